@@ -1,0 +1,739 @@
+/*
+ * fqz_entropy.c — oracle for the entropy stage ("FQZ-H1" profile).
+ *
+ * TEST INFRASTRUCTURE ONLY (see fqz_oracle.h).
+ *
+ * The reference pushes each of the six pre-entropy streams through
+ * zstd.Encoder.EncodeAll at SpeedFastest (/root/reference
+ * internal/compress/compress.go:115-118, 523-528) and reads them back with
+ * zstd.Decoder.DecodeAll (compress.go:785-814).  That library
+ * (github.com/klauspost/compress v1.19.1, go.mod:8) is not on disk; its
+ * compressed bytes are pinned by no reference test ("parity unpinned").  What
+ * IS a contract is the wire format: each payload is a zstd frame (RFC 8878).
+ * This file restates the published format for the subset we emit:
+ *
+ *   frame  = magic 28 B5 2F FD | FHD 0x80 | Window_Descriptor 0x38 (128 KiB)
+ *            | Frame_Content_Size u32le | blocks...            (no checksum)
+ *   block  = one per FQZO_CHUNK (16 KiB) bytes of the stream, in order:
+ *            RLE block        when all bytes are equal,
+ *            Raw block        when m < 64 or Huffman does not shrink it,
+ *            Compressed block = Huffman-coded literals (1 stream if m < 256,
+ *            else 4 streams) + "0 sequences".
+ *   empty stream -> 0 bytes (klauspost EncodeAll without WithZeroFrames).
+ *
+ * The construction below is fully deterministic; the HIP encoder
+ * (fastqpacker_amd/csrc) implements the same steps and must match it
+ * byte-for-byte (tests/test_gpu_parity.py).
+ */
+#include "fqz_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define HUF_MAX_BITS 11
+#define FSE_W_MAXLOG 6
+
+static inline int highbit32(uint32_t v) { return 31 - __builtin_clz(v); }
+
+/* ===================================================================== */
+/* Huffman code lengths                                                   */
+/* ===================================================================== */
+
+static int cmp_u32(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return (x > y) - (x < y);
+}
+
+int fqzo_huf_code_lengths(const uint32_t count[256], uint8_t nbits[256])
+{
+    uint32_t key[256];
+    int n = 0;
+    memset(nbits, 0, 256);
+    for (int s = 0; s < 256; s++)
+        if (count[s]) key[n++] = (count[s] << 8) | (uint32_t)s; /* count <= 2^17 */
+    if (n < 2) return 0;
+    qsort(key, (size_t)n, sizeof key[0], cmp_u32); /* ascending (count, symbol): total order */
+
+    /* two-queue Huffman merge; leaf preferred on ties */
+    uint32_t cnt[512];
+    uint16_t parent[512];
+    for (int i = 0; i < n; i++) cnt[i] = key[i] >> 8;
+    int li = 0, ih = n, it = n; /* leaf head, internal head, internal tail */
+    for (int k = 0; k < n - 1; k++) {
+        int a, b;
+        if (li < n && (ih >= it || cnt[li] <= cnt[ih])) a = li++; else a = ih++;
+        if (li < n && (ih >= it || cnt[li] <= cnt[ih])) b = li++; else b = ih++;
+        cnt[it] = cnt[a] + cnt[b];
+        parent[a] = parent[b] = (uint16_t)it;
+        it++;
+    }
+    uint8_t depth[512];
+    int root = 2 * n - 2;
+    depth[root] = 0;
+    for (int v = root - 1; v >= 0; v--) depth[v] = (uint8_t)(depth[parent[v]] + 1);
+
+    uint8_t l[256];
+    int maxd = 0;
+    for (int i = 0; i < n; i++) { l[i] = depth[i]; if (l[i] > maxd) maxd = l[i]; }
+
+    if (maxd > HUF_MAX_BITS) {
+        /* length limiting: clamp, then repair the Kraft sum (unit 2^-11) */
+        int32_t K = 0;
+        for (int i = 0; i < n; i++) {
+            if (l[i] > HUF_MAX_BITS) l[i] = HUF_MAX_BITS;
+            K += 1 << (HUF_MAX_BITS - l[i]);
+        }
+        while (K > (1 << HUF_MAX_BITS)) {
+            int best = -1;
+            for (int i = 0; i < n; i++)
+                if (l[i] < HUF_MAX_BITS && (best < 0 || l[i] > l[best])) best = i;
+            l[best]++;
+            K -= 1 << (HUF_MAX_BITS - l[best]);
+        }
+        int32_t slack = (1 << HUF_MAX_BITS) - K;
+        while (slack > 0) {
+            for (int i = n - 1; i >= 0 && slack > 0; i--)
+                while (l[i] > 1 && (1 << (HUF_MAX_BITS - l[i])) <= slack) {
+                    slack -= 1 << (HUF_MAX_BITS - l[i]);
+                    l[i]--;
+                }
+        }
+        maxd = 0;
+        for (int i = 0; i < n; i++) if (l[i] > maxd) maxd = l[i];
+    }
+    for (int i = 0; i < n; i++) nbits[key[i] & 0xFF] = l[i];
+    return maxd;
+}
+
+void fqzo_huf_codes(const uint8_t nbits[256], int max_bits, uint16_t code[256])
+{
+    /* RFC 8878 4.2.1.3: codes handed out from the longest length upward, in
+     * symbol order within a length. */
+    uint32_t nb_per_rank[HUF_MAX_BITS + 2] = {0}, val_per_rank[HUF_MAX_BITS + 2] = {0};
+    for (int s = 0; s < 256; s++) nb_per_rank[nbits[s]]++;
+    uint32_t min = 0;
+    for (int n = max_bits; n > 0; n--) {
+        val_per_rank[n] = min;
+        min += nb_per_rank[n];
+        min >>= 1;
+    }
+    for (int s = 0; s < 256; s++) code[s] = nbits[s] ? (uint16_t)val_per_rank[nbits[s]]++ : 0;
+}
+
+/* ===================================================================== */
+/* FSE for the Huffman weights (RFC 8878 4.1 / 4.2.1.2)                   */
+/* ===================================================================== */
+
+typedef struct {
+    uint8_t *p;
+    uint64_t acc;
+    int nb;
+} bitw;
+static inline void bw_add(bitw *b, uint32_t v, int n)
+{
+    b->acc |= (uint64_t)v << b->nb;
+    b->nb += n;
+    while (b->nb >= 8) { *b->p++ = (uint8_t)b->acc; b->acc >>= 8; b->nb -= 8; }
+}
+static inline uint8_t *bw_close(bitw *b) /* end mark 1 + pad */
+{
+    bw_add(b, 1, 1);
+    if (b->nb) { *b->p++ = (uint8_t)b->acc; b->acc = 0; b->nb = 0; }
+    return b->p;
+}
+
+/* returns compressed size, 0 = not compressible, 1 = single symbol (caller falls back) */
+static size_t fse_compress_weights(const uint8_t *w, int n, uint8_t *dst)
+{
+    if (n <= 1) return 0;
+    int cnt[13] = {0}, maxw = 0, maxc = 0;
+    for (int i = 0; i < n; i++) { cnt[w[i]]++; if (w[i] > maxw) maxw = w[i]; }
+    for (int s = 0; s <= maxw; s++) if (cnt[s] > maxc) maxc = cnt[s];
+    if (maxc == n) return 1;
+    if (maxc == 1) return 0;
+
+    /* table log as FSE_optimalTableLog(6, n, maxw) */
+    int table_log = FSE_W_MAXLOG;
+    {
+        int max_bits_src = highbit32((uint32_t)(n - 1)) - 2;
+        int min_bits_src = highbit32((uint32_t)n) + 1;
+        int min_bits_sym = highbit32((uint32_t)maxw) + 2;
+        int min_bits = min_bits_src < min_bits_sym ? min_bits_src : min_bits_sym;
+        if (max_bits_src < table_log) table_log = max_bits_src;
+        if (min_bits > table_log) table_log = min_bits;
+        if (table_log < 5) table_log = 5;
+        if (table_log > FSE_W_MAXLOG) table_log = FSE_W_MAXLOG;
+    }
+    int table_size = 1 << table_log;
+
+    /* normalisation (ours): every present symbol gets 1, the rest pro rata,
+     * leftover to the most frequent (lowest symbol on ties) */
+    int norm[13] = {0}, present = 0, largest = 0;
+    for (int s = 0; s <= maxw; s++) {
+        if (cnt[s]) present++;
+        if (cnt[s] > cnt[largest]) largest = s;
+    }
+    int R = table_size - present, given = 0;
+    for (int s = 0; s <= maxw; s++)
+        if (cnt[s]) { int e = (cnt[s] * R) / n; norm[s] = 1 + e; given += e; }
+    norm[largest] += R - given;
+
+    /* FSE_writeNCount */
+    uint8_t *op = dst;
+    {
+        uint32_t bits = 0;
+        int bc = 0;
+        int remaining = table_size + 1, threshold = table_size, nb = table_log + 1;
+        int sym = 0, alphabet = maxw + 1, prev0 = 0;
+        bits += (uint32_t)(table_log - 5) << bc; bc += 4;
+        while (sym < alphabet && remaining > 1) {
+            if (prev0) {
+                int start = sym;
+                while (sym < alphabet && !norm[sym]) sym++;
+                if (sym == alphabet) break;
+                while (sym >= start + 3) { start += 3; bits += 3u << bc; bc += 2; }
+                bits += (uint32_t)(sym - start) << bc; bc += 2;
+                if (bc > 16) { *op++ = (uint8_t)bits; *op++ = (uint8_t)(bits >> 8); bits >>= 16; bc -= 16; }
+            }
+            {
+                int c = norm[sym++];
+                int max = (2 * threshold - 1) - remaining;
+                remaining -= c;
+                c++;
+                if (c >= threshold) c += max;
+                bits += (uint32_t)c << bc;
+                bc += nb;
+                bc -= (c < max);
+                prev0 = (c == 1);
+                while (remaining < threshold) { nb--; threshold >>= 1; }
+            }
+            if (bc > 16) { *op++ = (uint8_t)bits; *op++ = (uint8_t)(bits >> 8); bits >>= 16; bc -= 16; }
+        }
+        if (bc > 0) *op++ = (uint8_t)bits;
+        if (bc > 8) *op++ = (uint8_t)(bits >> 8);
+    }
+
+    /* FSE_buildCTable */
+    uint16_t state_table[64];
+    uint8_t table_symbol[64];
+    int32_t delta_nb[13], delta_find[13];
+    {
+        int cumul[14];
+        cumul[0] = 0;
+        for (int s = 1; s <= maxw + 1; s++) cumul[s] = cumul[s - 1] + norm[s - 1];
+        int step = (table_size >> 1) + (table_size >> 3) + 3, mask = table_size - 1, pos = 0;
+        for (int s = 0; s <= maxw; s++)
+            for (int i = 0; i < norm[s]; i++) { table_symbol[pos] = (uint8_t)s; pos = (pos + step) & mask; }
+        for (int u = 0; u < table_size; u++) { int s = table_symbol[u]; state_table[cumul[s]++] = (uint16_t)(table_size + u); }
+        int total = 0;
+        for (int s = 0; s <= maxw; s++) {
+            if (norm[s] == 0) { delta_nb[s] = ((table_log + 1) << 16) - table_size; delta_find[s] = 0; }
+            else if (norm[s] == 1) { delta_nb[s] = (table_log << 16) - table_size; delta_find[s] = total - 1; total++; }
+            else {
+                int max_bits_out = table_log - highbit32((uint32_t)(norm[s] - 1));
+                int min_state_plus = norm[s] << max_bits_out;
+                delta_nb[s] = (max_bits_out << 16) - min_state_plus;
+                delta_find[s] = total - norm[s];
+                total += norm[s];
+            }
+        }
+    }
+
+    /* encode backwards with two states: state1 = even positions, state2 = odd */
+    bitw bw = { op, 0, 0 };
+    uint32_t st[2];
+    int inited[2] = {0, 0};
+    for (int i = n - 1; i >= 0; i--) {
+        int which = i & 1, s = w[i];
+        if (!inited[which]) { /* FSE_initCState2 */
+            uint32_t nb_out = (uint32_t)(delta_nb[s] + (1 << 15)) >> 16;
+            uint32_t value = (nb_out << 16) - (uint32_t)delta_nb[s];
+            st[which] = state_table[(value >> nb_out) + delta_find[s]];
+            inited[which] = 1;
+        } else {
+            uint32_t nb_out = (st[which] + (uint32_t)delta_nb[s]) >> 16;
+            bw_add(&bw, st[which] & ((1u << nb_out) - 1), (int)nb_out);
+            st[which] = state_table[(st[which] >> nb_out) + delta_find[s]];
+        }
+    }
+    bw_add(&bw, st[1] & (uint32_t)(table_size - 1), table_log); /* flush state2 then state1 */
+    bw_add(&bw, st[0] & (uint32_t)(table_size - 1), table_log);
+    op = bw_close(&bw);
+    return (size_t)(op - dst);
+}
+
+size_t fqzo_huf_write_tree(const uint8_t nbits[256], int max_bits, uint8_t *dst)
+{
+    int max_sym = 255;
+    while (max_sym > 0 && !nbits[max_sym]) max_sym--;
+    int nw = max_sym; /* weights for symbols 0..max_sym-1; the last is implied */
+    uint8_t w[256];
+    for (int s = 0; s < nw; s++) w[s] = nbits[s] ? (uint8_t)(max_bits + 1 - nbits[s]) : 0;
+    uint8_t tmp[300];
+    size_t h = fse_compress_weights(w, nw, tmp);
+    if (h > 1 && h < (size_t)nw / 2) {
+        dst[0] = (uint8_t)h;
+        memcpy(dst + 1, tmp, h);
+        return h + 1;
+    }
+    if (nw > 128) return 0;
+    dst[0] = (uint8_t)(128 + (nw - 1));
+    w[nw] = 0;
+    for (int i = 0; i < nw; i += 2) dst[i / 2 + 1] = (uint8_t)((w[i] << 4) + w[i + 1]);
+    return (size_t)((nw + 1) / 2) + 1;
+}
+
+/* ===================================================================== */
+/* one zstd block per chunk                                               */
+/* ===================================================================== */
+
+static inline void put_block_header(uint8_t *dst, int last, int type, uint32_t size)
+{
+    uint32_t v = (uint32_t)(last & 1) | ((uint32_t)type << 1) | (size << 3);
+    dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+}
+
+static size_t raw_block(const uint8_t *src, size_t m, int last, uint8_t *dst)
+{
+    put_block_header(dst, last, 0, (uint32_t)m);
+    memcpy(dst + 3, src, m);
+    return 3 + m;
+}
+
+/* HUF 1X stream: symbols written last-to-first, then the end mark */
+static size_t huf_stream(const uint8_t *src, size_t n, const uint16_t *code, const uint8_t *nbits, uint8_t *dst)
+{
+    bitw bw = { dst, 0, 0 };
+    for (size_t i = n; i-- > 0;) bw_add(&bw, code[src[i]], nbits[src[i]]);
+    return (size_t)(bw_close(&bw) - dst);
+}
+
+size_t fqzo_encode_chunk(const uint8_t *src, size_t m, int last, uint8_t *dst)
+{
+    uint32_t count[256] = {0};
+    for (size_t i = 0; i < m; i++) count[src[i]]++;
+    if (count[src[0]] == m) { /* RLE block */
+        put_block_header(dst, last, 1, (uint32_t)m);
+        dst[3] = src[0];
+        return 4;
+    }
+    if (m < 64) return raw_block(src, m, last, dst);
+
+    uint8_t nbits[256];
+    uint16_t code[256];
+    int max_bits = fqzo_huf_code_lengths(count, nbits);
+    uint8_t tree[260];
+    size_t tree_size = fqzo_huf_write_tree(nbits, max_bits, tree);
+    if (!tree_size) return raw_block(src, m, last, dst);
+    fqzo_huf_codes(nbits, max_bits, code);
+
+    int nstreams = m >= 256 ? 4 : 1;
+    size_t seg = nstreams == 4 ? (m + 3) / 4 : m;
+    size_t ssize[4] = {0, 0, 0, 0}, streams_total = 0;
+    for (int k = 0; k < nstreams; k++) {
+        size_t a = (size_t)k * seg, b = (k == nstreams - 1) ? m : a + seg;
+        uint64_t bits = 0;
+        for (size_t i = a; i < b; i++) bits += nbits[src[i]];
+        ssize[k] = (size_t)(bits >> 3) + 1;
+        streams_total += ssize[k];
+    }
+    size_t lit_csize = tree_size + (nstreams == 4 ? 6 : 0) + streams_total;
+    size_t lh = m < 1024 ? 3 : (m < 16384 ? 4 : 5);
+    size_t content = lh + lit_csize + 1;
+    if (content >= m) return raw_block(src, m, last, dst);
+
+    put_block_header(dst, last, 2, (uint32_t)content);
+    uint8_t *op = dst + 3;
+    if (lh == 3) {
+        uint32_t v = 2u | ((nstreams == 4 ? 1u : 0u) << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 14);
+        op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16);
+    } else if (lh == 4) {
+        uint32_t v = 2u | (2u << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 18);
+        op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); op[3] = (uint8_t)(v >> 24);
+    } else {
+        uint32_t v = 2u | (3u << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 22);
+        op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); op[3] = (uint8_t)(v >> 24);
+        op[4] = (uint8_t)(lit_csize >> 10);
+    }
+    op += lh;
+    memcpy(op, tree, tree_size);
+    op += tree_size;
+    if (nstreams == 4) {
+        for (int k = 0; k < 3; k++) { op[2 * k] = (uint8_t)ssize[k]; op[2 * k + 1] = (uint8_t)(ssize[k] >> 8); }
+        op += 6;
+    }
+    for (int k = 0; k < nstreams; k++) {
+        size_t a = (size_t)k * seg, b = (k == nstreams - 1) ? m : a + seg;
+        size_t w = huf_stream(src + a, b - a, code, nbits, op);
+        (void)w;
+        op += ssize[k];
+    }
+    *op++ = 0; /* Number_of_Sequences = 0 */
+    return (size_t)(op - dst);
+}
+
+/* ===================================================================== */
+/* frame                                                                  */
+/* ===================================================================== */
+
+size_t fqzo_entropy_bound(size_t n)
+{
+    if (!n) return 0;
+    size_t chunks = (n + FQZO_CHUNK - 1) / FQZO_CHUNK;
+    return 10 + n + 3 * chunks;
+}
+
+size_t fqzo_entropy_encode(const uint8_t *src, size_t n, uint8_t *dst)
+{
+    if (!n) return 0;
+    uint8_t *op = dst;
+    op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
+    op[4] = 0x80; /* FCS 4 bytes, not single-segment, no checksum, no dict */
+    op[5] = 0x38; /* window 128 KiB */
+    op[6] = (uint8_t)n; op[7] = (uint8_t)(n >> 8); op[8] = (uint8_t)(n >> 16); op[9] = (uint8_t)(n >> 24);
+    op += 10;
+    for (size_t off = 0; off < n; off += FQZO_CHUNK) {
+        size_t m = n - off < FQZO_CHUNK ? n - off : FQZO_CHUNK;
+        op += fqzo_encode_chunk(src + off, m, off + m == n, op);
+    }
+    return (size_t)(op - dst);
+}
+
+/* ===================================================================== */
+/* decoder (subset: no sequences)                                         */
+/* ===================================================================== */
+
+/* backward bit reader over [p, p+n) */
+typedef struct {
+    const uint8_t *p;
+    size_t n;
+    long pos; /* number of unread bits */
+} bitr;
+static int br_init(bitr *b, const uint8_t *p, size_t n)
+{
+    if (!n || !p[n - 1]) return -1;
+    b->p = p;
+    b->n = n;
+    b->pos = (long)(n - 1) * 8 + highbit32(p[n - 1]);
+    return 0;
+}
+/* peek nb (<= 16) bits just below pos (zero-padded below bit 0) */
+static inline uint32_t br_peek(const bitr *b, int nb)
+{
+    long lo = b->pos - nb;
+    if (lo >= 0 && (size_t)(lo >> 3) + 4 <= b->n) {
+        uint32_t x;
+        memcpy(&x, b->p + (lo >> 3), 4); /* little-endian host */
+        return (x >> (lo & 7)) & ((1u << nb) - 1);
+    }
+    uint32_t v = 0;
+    for (int i = nb - 1; i >= 0; i--) {
+        long bit = lo + i;
+        uint32_t x = bit >= 0 ? (uint32_t)(b->p[bit >> 3] >> (bit & 7)) & 1u : 0u;
+        v = (v << 1) | x;
+    }
+    return v;
+}
+static inline uint32_t br_read(bitr *b, int nb)
+{
+    uint32_t v = br_peek(b, nb);
+    b->pos -= nb;
+    return v;
+}
+
+/* FSE_readNCount + decode of the weight stream; returns number of weights or -1 */
+static int fse_decode_weights(const uint8_t *src, size_t n, uint8_t *w, int cap)
+{
+    if (n < 2) return -1;
+    /* read NCount with a forward bit reader */
+    uint64_t acc = 0;
+    size_t avail_bits = n * 8, bitpos = 0;
+#define NC_PEEK(nb) ((uint32_t)({ uint64_t _v = 0; for (int _i = 0; _i < 4; _i++) { size_t _b = (bitpos >> 3) + (size_t)_i; if (_b < n) _v |= (uint64_t)src[_b] << (8 * _i); } (_v >> (bitpos & 7)) & ((1u << (nb)) - 1); }))
+    (void)acc;
+    int table_log = (int)NC_PEEK(4) + 5;
+    bitpos += 4;
+    if (table_log > FSE_W_MAXLOG) return -1;
+    int table_size = 1 << table_log;
+    int remaining = table_size + 1, threshold = table_size, nb = table_log + 1;
+    int norm[256], sym = 0, prev0 = 0;
+    while (remaining > 1 && sym <= 255) {
+        if (prev0) {
+            int n0 = sym;
+            for (;;) {
+                uint32_t r = NC_PEEK(2);
+                bitpos += 2;
+                n0 += (int)r;
+                if (r != 3) break;
+            }
+            if (n0 > 255) return -1;
+            while (sym < n0) norm[sym++] = 0;
+        }
+        int max = (2 * threshold - 1) - remaining;
+        int count;
+        uint32_t lowv = NC_PEEK(nb - 1);
+        if ((int)lowv < max) { count = (int)lowv; bitpos += (size_t)(nb - 1); }
+        else {
+            count = (int)NC_PEEK(nb);
+            if (count >= threshold) count -= max;
+            bitpos += (size_t)nb;
+        }
+        count--;
+        remaining -= count < 0 ? -count : count;
+        norm[sym++] = count;
+        prev0 = !count;
+        while (remaining < threshold) { nb--; threshold >>= 1; }
+        if (bitpos > avail_bits) return -1;
+    }
+#undef NC_PEEK
+    if (remaining != 1) return -1;
+    int max_sv = sym - 1;
+    size_t hdr = (bitpos + 7) >> 3;
+    if (hdr >= n) return -1;
+
+    /* FSE_buildDTable */
+    uint8_t dsym[64], dnb[64];
+    uint16_t dnew[64];
+    {
+        uint16_t next[256];
+        int high = table_size - 1;
+        for (int s = 0; s <= max_sv; s++) {
+            if (norm[s] == -1) { dsym[high--] = (uint8_t)s; next[s] = 1; }
+            else next[s] = (uint16_t)norm[s];
+        }
+        int step = (table_size >> 1) + (table_size >> 3) + 3, mask = table_size - 1, pos = 0;
+        for (int s = 0; s <= max_sv; s++)
+            for (int i = 0; i < norm[s]; i++) {
+                dsym[pos] = (uint8_t)s;
+                pos = (pos + step) & mask;
+                while (pos > high) pos = (pos + step) & mask;
+            }
+        if (pos != 0) return -1;
+        for (int u = 0; u < table_size; u++) {
+            int s = dsym[u];
+            uint32_t ns = next[s]++;
+            dnb[u] = (uint8_t)(table_log - highbit32(ns));
+            dnew[u] = (uint16_t)((ns << dnb[u]) - (uint32_t)table_size);
+        }
+    }
+    bitr br;
+    if (br_init(&br, src + hdr, n - hdr) < 0) return -1;
+    if (br.pos < 2 * table_log) return -1;
+    uint32_t s1 = br_read(&br, table_log), s2 = br_read(&br, table_log);
+    int out = 0;
+    for (;;) {
+        /* mirrors FSE_decompress_usingDTable_generic's tail handling */
+        if (out >= cap) return -1;
+        w[out++] = dsym[s1];
+        if (br.pos < dnb[s1]) { if (out >= cap) return -1; w[out++] = dsym[s2]; break; }
+        s1 = dnew[s1] + br_read(&br, dnb[s1]);
+        if (out >= cap) return -1;
+        w[out++] = dsym[s2];
+        if (br.pos < dnb[s2]) { if (out >= cap) return -1; w[out++] = dsym[s1]; break; }
+        s2 = dnew[s2] + br_read(&br, dnb[s2]);
+    }
+    return out;
+}
+
+typedef struct { uint8_t sym, nb; } hdec;
+
+/* Huffman_Tree_Description -> decode table; returns bytes consumed or -1 */
+static long huf_read_table(const uint8_t *src, size_t n, hdec *dt, int *table_log_out)
+{
+    if (!n) return -1;
+    uint8_t w[256];
+    int nw;
+    size_t used;
+    uint8_t hb = src[0];
+    if (hb >= 128) {
+        nw = hb - 127;
+        used = 1 + (size_t)(nw + 1) / 2;
+        if (used > n) return -1;
+        for (int i = 0; i < nw; i += 2) {
+            w[i] = src[1 + i / 2] >> 4;
+            if (i + 1 < nw) w[i + 1] = src[1 + i / 2] & 15;
+        }
+    } else {
+        used = 1 + (size_t)hb;
+        if (used > n) return -1;
+        nw = fse_decode_weights(src + 1, hb, w, 255);
+        if (nw < 0) return -1;
+    }
+    uint32_t total = 0;
+    for (int i = 0; i < nw; i++) {
+        if (w[i] > 12) return -1;
+        total += (1u << w[i]) >> 1;
+    }
+    if (!total) return -1;
+    int table_log = highbit32(total) + 1;
+    if (table_log > 12) return -1;
+    uint32_t rest = (1u << table_log) - total;
+    if (rest & (rest - 1)) return -1; /* must be a power of two */
+    w[nw] = (uint8_t)(highbit32(rest) + 1);
+    nw++;
+    uint32_t rank_start[14] = {0}, rank_cnt[14] = {0};
+    for (int i = 0; i < nw; i++) rank_cnt[w[i]]++;
+    if (rank_cnt[1] < 2 || (rank_cnt[1] & 1)) return -1;
+    uint32_t next = 0;
+    for (int r = 1; r <= table_log; r++) { rank_start[r] = next; next += rank_cnt[r] << (r - 1); }
+    for (int s = 0; s < nw; s++) {
+        if (!w[s]) continue;
+        uint32_t len = (1u << w[s]) >> 1;
+        for (uint32_t u = 0; u < len; u++) { dt[rank_start[w[s]] + u].sym = (uint8_t)s; dt[rank_start[w[s]] + u].nb = (uint8_t)(table_log + 1 - w[s]); }
+        rank_start[w[s]] += len;
+    }
+    *table_log_out = table_log;
+    return (long)used;
+}
+
+static int huf_decode_stream(const uint8_t *src, size_t n, const hdec *dt, int table_log, uint8_t *dst, size_t count)
+{
+    bitr br;
+    if (br_init(&br, src, n) < 0) return -1;
+    for (size_t i = 0; i < count; i++) {
+        uint32_t v = br_peek(&br, table_log);
+        dst[i] = dt[v].sym;
+        br.pos -= dt[v].nb;
+        if (br.pos < 0) return -1;
+    }
+    return br.pos == 0 ? 0 : -1;
+}
+
+/* literals section of a Compressed block; block must regenerate exactly the literals */
+static long decode_compressed_block(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
+{
+    if (n < 2) return FQZO_E_ENTROPY;
+    int type = src[0] & 3, fmt = (src[0] >> 2) & 3;
+    size_t lh, regen, csize = 0;
+    int nstreams = 1;
+    if (type == 0 || type == 1) { /* Raw / RLE literals */
+        if (fmt == 0 || fmt == 2) { lh = 1; regen = src[0] >> 3; }
+        else if (fmt == 1) { lh = 2; regen = (src[0] >> 4) | ((size_t)src[1] << 4); }
+        else { if (n < 3) return FQZO_E_ENTROPY; lh = 3; regen = (src[0] >> 4) | ((size_t)src[1] << 4) | ((size_t)src[2] << 12); }
+        if (regen > cap) return FQZO_E_DST_SMALL;
+        if (type == 0) {
+            if (lh + regen + 1 > n) return FQZO_E_ENTROPY;
+            memcpy(dst, src + lh, regen);
+            csize = regen;
+        } else {
+            if (lh + 1 + 1 > n) return FQZO_E_ENTROPY;
+            memset(dst, src[lh], regen);
+            csize = 1;
+        }
+    } else if (type == 2) {
+        if (fmt <= 1) {
+            if (n < 3) return FQZO_E_ENTROPY;
+            uint32_t v = src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16);
+            lh = 3; regen = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; nstreams = fmt ? 4 : 1;
+        } else if (fmt == 2) {
+            if (n < 4) return FQZO_E_ENTROPY;
+            uint32_t v = src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
+            lh = 4; regen = (v >> 4) & 0x3FFF; csize = v >> 18; nstreams = 4;
+        } else {
+            if (n < 5) return FQZO_E_ENTROPY;
+            uint64_t v = src[0] | ((uint64_t)src[1] << 8) | ((uint64_t)src[2] << 16) | ((uint64_t)src[3] << 24) | ((uint64_t)src[4] << 32);
+            lh = 5; regen = (size_t)((v >> 4) & 0x3FFFF); csize = (size_t)(v >> 22); nstreams = 4;
+        }
+        if (regen > cap) return FQZO_E_DST_SMALL;
+        if (lh + csize + 1 > n) return FQZO_E_ENTROPY;
+        const uint8_t *ip = src + lh;
+        hdec dt[4096];
+        int table_log;
+        long used = huf_read_table(ip, csize, dt, &table_log);
+        if (used < 0) return FQZO_E_ENTROPY;
+        ip += used;
+        size_t rem = csize - (size_t)used;
+        if (nstreams == 1) {
+            if (huf_decode_stream(ip, rem, dt, table_log, dst, regen) < 0) return FQZO_E_ENTROPY;
+        } else {
+            if (rem < 10) return FQZO_E_ENTROPY;
+            size_t s1 = ip[0] | ((size_t)ip[1] << 8), s2 = ip[2] | ((size_t)ip[3] << 8), s3 = ip[4] | ((size_t)ip[5] << 8);
+            if (6 + s1 + s2 + s3 >= rem) return FQZO_E_ENTROPY;
+            size_t s4 = rem - 6 - s1 - s2 - s3;
+            size_t seg = (regen + 3) / 4;
+            if (3 * seg > regen) return FQZO_E_ENTROPY;
+            const uint8_t *p = ip + 6;
+            if (huf_decode_stream(p, s1, dt, table_log, dst, seg) < 0) return FQZO_E_ENTROPY;
+            if (huf_decode_stream(p + s1, s2, dt, table_log, dst + seg, seg) < 0) return FQZO_E_ENTROPY;
+            if (huf_decode_stream(p + s1 + s2, s3, dt, table_log, dst + 2 * seg, seg) < 0) return FQZO_E_ENTROPY;
+            if (huf_decode_stream(p + s1 + s2 + s3, s4, dt, table_log, dst + 3 * seg, regen - 3 * seg) < 0) return FQZO_E_ENTROPY;
+        }
+    } else {
+        return FQZO_E_ENTROPY; /* treeless literals: never emitted by us */
+    }
+    /* sequences section: must say 0 sequences and end the block */
+    if (lh + csize + 1 != n || src[lh + csize] != 0) return FQZO_E_ENTROPY;
+    return (long)regen;
+}
+
+static int parse_frame_header(const uint8_t *src, size_t n, size_t *hdr_size, long *fcs, int *has_checksum)
+{
+    if (n < 6) return -1;
+    if (!(src[0] == 0x28 && src[1] == 0xB5 && src[2] == 0x2F && src[3] == 0xFD)) return -1;
+    uint8_t fhd = src[4];
+    int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, dict = fhd & 3;
+    if (fhd & 0x08) return -1; /* reserved bit */
+    *has_checksum = (fhd >> 2) & 1;
+    size_t p = 5;
+    if (!single) p += 1;
+    static const int dict_sz[4] = {0, 1, 2, 4};
+    p += (size_t)dict_sz[dict];
+    int fcs_sz = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+    if (p + (size_t)fcs_sz > n) return -1;
+    *fcs = -1;
+    if (fcs_sz) {
+        uint64_t v = 0;
+        for (int i = 0; i < fcs_sz; i++) v |= (uint64_t)src[p + (size_t)i] << (8 * i);
+        if (fcs_sz == 2) v += 256;
+        *fcs = (long)v;
+    }
+    *hdr_size = p + (size_t)fcs_sz;
+    return 0;
+}
+
+long fqzo_entropy_content_size(const uint8_t *src, size_t n)
+{
+    if (!n) return 0;
+    size_t h; long fcs; int ck;
+    if (parse_frame_header(src, n, &h, &fcs, &ck) < 0) return FQZO_E_ENTROPY;
+    return fcs;
+}
+
+long fqzo_entropy_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
+{
+    size_t out = 0;
+    size_t ip = 0;
+    while (ip < n) { /* concatenated frames are legal; DecodeAll decodes them all */
+        size_t h; long fcs; int ck;
+        if (parse_frame_header(src + ip, n - ip, &h, &fcs, &ck) < 0) return FQZO_E_ENTROPY;
+        ip += h;
+        size_t frame_start = out;
+        for (;;) {
+            if (ip + 3 > n) return FQZO_E_ENTROPY;
+            uint32_t bh = src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16);
+            ip += 3;
+            int last = bh & 1, type = (bh >> 1) & 3;
+            size_t bs = bh >> 3;
+            if (type == 0) {
+                if (ip + bs > n) return FQZO_E_ENTROPY;
+                if (out + bs > cap) return FQZO_E_DST_SMALL;
+                memcpy(dst + out, src + ip, bs);
+                ip += bs; out += bs;
+            } else if (type == 1) {
+                if (ip + 1 > n) return FQZO_E_ENTROPY;
+                if (out + bs > cap) return FQZO_E_DST_SMALL;
+                memset(dst + out, src[ip], bs);
+                ip += 1; out += bs;
+            } else if (type == 2) {
+                if (ip + bs > n || bs > 128 * 1024) return FQZO_E_ENTROPY;
+                long r = decode_compressed_block(src + ip, bs, dst + out, cap - out);
+                if (r < 0) return r;
+                ip += bs; out += (size_t)r;
+            } else return FQZO_E_ENTROPY;
+            if (last) break;
+        }
+        if (ck) { if (ip + 4 > n) return FQZO_E_ENTROPY; ip += 4; /* XXH64 low 32 bits: not verified */ }
+        if (fcs >= 0 && (size_t)fcs != out - frame_start) return FQZO_E_ENTROPY;
+    }
+    return (long)out;
+}
