@@ -1,0 +1,129 @@
+"""Mirror of internal/compress (Compress / Decompress / Options) plus the per-block and
+device-resident batch entry points of libfqzhip.  All codec work runs on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import (lib, check, default_ctx, BatchResult, Options, DecompressOptions, FqzError, DEFAULT_BLOCK_SIZE,
+                   DETECT_ENCODING, BATCH_FINAL, SynthParams)
+
+DefaultBlockSize = DEFAULT_BLOCK_SIZE  # compress.go:71
+
+
+def _as_u8(buf):
+    if isinstance(buf, np.ndarray):
+        return np.ascontiguousarray(buf, dtype=np.uint8)
+    return np.frombuffer(buf, dtype=np.uint8)
+
+
+def Compress(fastq, opts: Options = None, ctx=None) -> bytes:
+    """compress.Compress (compress.go:125): FASTQ bytes -> .fqz bytes."""
+    ctx = ctx or default_ctx()
+    a = _as_u8(fastq)
+    cap = lib().fqz_encode_bound(a.size) + 10
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    check(lib().fqz_compress(ctx.handle, a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, C.byref(n),
+                             C.byref(opts) if opts is not None else None))
+    return out[: n.value].tobytes()
+
+
+def Decompress(fqz, opts: DecompressOptions = None, ctx=None) -> bytes:
+    """compress.Decompress (compress.go:558): .fqz bytes -> FASTQ bytes."""
+    ctx = ctx or default_ctx()
+    a = _as_u8(fqz)
+    n = C.c_size_t(0)
+    o = C.byref(opts) if opts is not None else None
+    check(lib().fqz_decompress(ctx.handle, a.ctypes.data if a.size else None, a.size, None, 0, C.byref(n), o))
+    out = np.empty(max(n.value, 1), dtype=np.uint8)
+    check(lib().fqz_decompress(ctx.handle, a.ctypes.data, a.size, out.ctypes.data, n.value, C.byref(n), o))
+    return out[: n.value].tobytes()
+
+
+def encode_block(fastq, qual_encoding=0, ctx=None):
+    """One call per block = compressBlockWithBuffers (compress.go:471). Returns (block bytes, n_records)."""
+    ctx = ctx or default_ctx()
+    a = _as_u8(fastq)
+    cap = lib().fqz_encode_bound(a.size)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    nrec = C.c_uint32(0)
+    check(lib().fqz_encode_block(ctx.handle, a.ctypes.data if a.size else None, a.size, qual_encoding, out.ctypes.data, cap,
+                                 C.byref(n), C.byref(nrec)))
+    return out[: n.value].tobytes(), nrec.value
+
+
+def decode_block(block, version=2, qual_encoding=0, ctx=None) -> bytes:
+    """decompressJobToPooledBuffer (compress.go:780): block header + payloads -> FASTQ text."""
+    ctx = ctx or default_ctx()
+    a = _as_u8(block)
+    n = C.c_size_t(0)
+    check(lib().fqz_decode_block_size(ctx.handle, a.ctypes.data, a.size, version, C.byref(n)))
+    out = np.empty(max(n.value, 1), dtype=np.uint8)
+    check(lib().fqz_decode_block(ctx.handle, a.ctypes.data, a.size, version, qual_encoding, out.ctypes.data, n.value, C.byref(n)))
+    return out[: n.value].tobytes()
+
+
+def get_streams(block=0, ctx=None):
+    """Test hook: the six pre-entropy streams of `block` of the last encode call."""
+    ctx = ctx or default_ctx()
+    lens = (C.c_size_t * 6)(*([0] * 6))
+    check(lib().fqz_debug_get_streams(ctx.handle, block, None, lens))
+    bufs = [C.create_string_buffer(max(1, lens[k])) for k in range(6)]
+    ptrs = (C.c_void_p * 6)(*[C.cast(b, C.c_void_p) for b in bufs])
+    caps = (C.c_size_t * 6)(*[max(1, lens[k]) for k in range(6)])
+    check(lib().fqz_debug_get_streams(ctx.handle, block, ptrs, caps))
+    return [bufs[k].raw[: caps[k]] for k in range(6)]
+
+
+def entropy_encode(data: bytes, ctx=None) -> bytes:
+    ctx = ctx or default_ctx()
+    cap = lib().fqz_entropy_bound(len(data)) + 16
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t(0)
+    check(lib().fqz_entropy_encode(ctx.handle, data, len(data), out, cap, C.byref(n)))
+    return out.raw[: n.value]
+
+
+def entropy_decode(frame: bytes, cap: int, ctx=None) -> bytes:
+    ctx = ctx or default_ctx()
+    out = C.create_string_buffer(max(cap, 1))
+    n = C.c_size_t(0)
+    check(lib().fqz_entropy_decode(ctx.handle, frame, len(frame), out, cap, C.byref(n)))
+    return out.raw[: n.value]
+
+
+def encode_batch_dev(d_fastq_ptr, n_bytes, d_out_ptr, out_cap, records_per_block=DEFAULT_BLOCK_SIZE,
+                     qual_encoding=DETECT_ENCODING, final=True, stream=None, ctx=None, max_blocks=0):
+    """Device-resident batch encode; pointers are raw device addresses (e.g. torch tensor.data_ptr())."""
+    ctx = ctx or default_ctx()
+    res = BatchResult()
+    offs = (C.c_uint64 * max_blocks)() if max_blocks else None
+    lens = (C.c_uint64 * max_blocks)() if max_blocks else None
+    rc = lib().fqz_encode_batch_dev(ctx.handle, d_fastq_ptr, n_bytes, records_per_block, qual_encoding, BATCH_FINAL if final else 0,
+                                    d_out_ptr, out_cap, C.byref(res), offs, lens, max_blocks, stream)
+    if rc:
+        raise FqzError(rc, "record %d" % res.error_record if res.status and -8 <= res.status <= -5 else "")
+    if max_blocks:
+        return res, list(offs[: res.n_blocks]), list(lens[: res.n_blocks])
+    return res
+
+
+def decode_batch_dev(d_blocks_ptr, n_bytes, d_out_ptr, out_cap, version=2, qual_encoding=0, stream=None, ctx=None):
+    ctx = ctx or default_ctx()
+    res = BatchResult()
+    check(lib().fqz_decode_batch_dev(ctx.handle, d_blocks_ptr, n_bytes, version, qual_encoding, d_out_ptr, out_cap, C.byref(res), stream))
+    return res
+
+
+def synth_fastq(n_records, seed=0xF0057A57, first_record=0, min_len=150, max_len=150, n_permille=0, phred=33, quality_profile=0,
+                cap=None):
+    """Deterministic synthetic FASTQ as a numpy uint8 array. Host generator."""
+    p = SynthParams(seed, first_record, min_len, max_len, n_permille, phred, quality_profile)
+    if cap is None:
+        cap = int(n_records) * (2 * max_len + 80) + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    wrote = C.c_uint64(0)
+    check(lib().fqz_synth_fastq(C.byref(p), n_records, out.ctypes.data, cap, C.byref(n), C.byref(wrote)))
+    return out[: n.value], wrote.value

@@ -1,0 +1,787 @@
+// fqz_api.hip — the extern "C" surface of libfqzhip (include/fqz.h).
+// Host logic mirrors internal/compress/compress.go (Compress :125, Decompress :558)
+// and internal/fqformat/container.go; all codec arithmetic runs in HIP kernels.
+#include "fqz_ctx.h"
+#include "fqz_device.h"
+
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+// ===========================================================================
+// errors
+// ===========================================================================
+static thread_local char g_hip_err[256] = "";
+
+int fqz_set_hip_error(hipError_t e, const char *what)
+{
+    snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) return FQZ_E_NO_DEVICE;
+    if (e == hipErrorOutOfMemory) return FQZ_E_NOMEM;
+    return FQZ_E_HIP;
+}
+
+extern "C" const char *fqz_last_hip_error(void) { return g_hip_err; }
+extern "C" const char *fqz_version(void) { return "libfqzhip 0.1.0 gfx950"; }
+
+extern "C" const char *fqz_strerror(int code)
+{
+    switch (code) {
+    case FQZ_OK: return "ok";
+    case FQZ_E_SHORT: return "unexpected EOF";
+    case FQZ_E_MAGIC: return "invalid magic bytes: not an FQZ file";
+    case FQZ_E_BLOCK_VERSION: return "unsupported block header version";
+    case FQZ_E_FILE_VERSION: return "unsupported file version";
+    case FQZ_E_HDR_AT: return "invalid FASTQ: header line must start with @";
+    case FQZ_E_SEP_PLUS: return "invalid FASTQ: separator line must start with +";
+    case FQZ_E_LEN_MISMATCH: return "invalid FASTQ: sequence and quality lengths must match";
+    case FQZ_E_LONG_N: return "sequence has ambiguous bases beyond position 65536; N-position tracking is limited to 65536 bp";
+    case FQZ_E_TRUNC_HEADER: return "truncated header data";
+    case FQZ_E_TRUNC_PLUS: return "truncated plus-line payload data";
+    case FQZ_E_TRUNC_SEQ: return "truncated sequence data";
+    case FQZ_E_TRUNC_QUAL: return "truncated quality data";
+    case FQZ_E_TRUNC_LEN: return "truncated length data";
+    case FQZ_E_TRUNC_NPOS: return "truncated N position data";
+    case FQZ_E_ENTROPY: return "decompressing stream: invalid or unsupported zstd frame";
+    case FQZ_E_READ_DATA: return "reading compressed data: unexpected EOF";
+    case FQZ_E_NOMEM: return "out of memory";
+    case FQZ_E_DST_SMALL: return "destination buffer too small";
+    case FQZ_E_FIELD_WRAP: return "header, plus-line payload or N count exceeds 65535 (u16 field would wrap)";
+    case FQZ_E_NPOS_RANGE: return "N position beyond read length";
+    case FQZ_E_HIP: return "HIP runtime error";
+    case FQZ_E_NO_DEVICE: return "no HIP device available (libfqzhip has no CPU fallback)";
+    case FQZ_E_ARG: return "invalid argument";
+    case FQZ_E_TOO_LARGE: return "batch too large for one device pass";
+    case FQZ_E_IO: return "I/O error";
+    default: return "unknown error";
+    }
+}
+
+// ===========================================================================
+// context
+// ===========================================================================
+extern "C" int fqz_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int fqz_ctx_create(int device, fqz_ctx **out)
+{
+    if (!out) return FQZ_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fqz_set_hip_error(e, "hipGetDeviceCount");
+    if (n <= 0) { snprintf(g_hip_err, sizeof g_hip_err, "no HIP device"); return FQZ_E_NO_DEVICE; }
+    if (device < 0 || device >= n) return FQZ_E_ARG;
+    HIP_TRY(hipSetDevice(device));
+    fqz_ctx *c = new (std::nothrow) fqz_ctx();
+    if (!c) return FQZ_E_NOMEM;
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fqz_set_hip_error(e, "hipStreamCreate"); }
+    *out = c;
+    return FQZ_OK;
+}
+
+extern "C" void fqz_ctx_destroy(fqz_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    EncState &e = c->enc;
+    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.partials};
+    for (DevBuf *b : eb) b->release();
+    e.h_info.release(); e.h_plans.release();
+    DecState &d = c->dec;
+    DevBuf *db[] = {&d.info, &d.blocks, &d.chunks, &d.streams, &d.rec, &d.partials, &d.tables};
+    for (DevBuf *b : db) b->release();
+    d.h_info.release(); d.h_blocks.release();
+    c->d_in.release(); c->d_out.release(); c->h_stage.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ===========================================================================
+// fqformat (container.go) — host side, byte-exact
+// ===========================================================================
+static inline void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+static inline uint32_t get32(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+extern "C" void fqz_write_file_header(const fqz_file_header *h, uint8_t out[10])
+{
+    out[0] = 'F'; out[1] = 'Q'; out[2] = 'Z'; out[3] = 0;
+    out[4] = h->version;
+    put32(out + 5, h->block_size);
+    out[9] = h->flags;
+}
+
+extern "C" int fqz_read_file_header(const uint8_t *in, size_t n, fqz_file_header *h)
+{
+    if (n < 4) return FQZ_E_SHORT;
+    if (!(in[0] == 'F' && in[1] == 'Q' && in[2] == 'Z' && in[3] == 0)) return FQZ_E_MAGIC;
+    if (n < 10) return FQZ_E_SHORT;
+    h->version = in[4];
+    h->block_size = get32(in + 5);
+    h->flags = in[9];
+    return FQZ_OK;
+}
+
+extern "C" int fqz_write_block_header(const fqz_block_header *b, uint8_t version, uint8_t *out)
+{
+    if (version == FQZ_VERSION1) {
+        const uint32_t v[8] = {b->num_records, b->seq_size, b->qual_size, b->header_size, b->npos_size, b->lengths_size,
+                               b->original_seq_size, b->original_qual_size};
+        for (int i = 0; i < 8; i++) put32(out + 4 * i, v[i]);
+        return 32;
+    }
+    if (version == FQZ_VERSION2) {
+        const uint32_t v[9] = {b->num_records, b->seq_size, b->qual_size, b->header_size, b->plus_size, b->npos_size,
+                               b->lengths_size, b->original_seq_size, b->original_qual_size};
+        for (int i = 0; i < 9; i++) put32(out + 4 * i, v[i]);
+        return 36;
+    }
+    return FQZ_E_BLOCK_VERSION;
+}
+
+extern "C" int fqz_read_block_header(const uint8_t *in, size_t n, uint8_t version, fqz_block_header *b)
+{
+    memset(b, 0, sizeof *b);
+    if (version == FQZ_VERSION1) {
+        if (n < 32) return FQZ_E_SHORT;
+        b->num_records = get32(in); b->seq_size = get32(in + 4); b->qual_size = get32(in + 8); b->header_size = get32(in + 12);
+        b->npos_size = get32(in + 16); b->lengths_size = get32(in + 20); b->original_seq_size = get32(in + 24);
+        b->original_qual_size = get32(in + 28);
+        return 32;
+    }
+    if (version == FQZ_VERSION2) {
+        if (n < 36) return FQZ_E_SHORT;
+        b->num_records = get32(in); b->seq_size = get32(in + 4); b->qual_size = get32(in + 8); b->header_size = get32(in + 12);
+        b->plus_size = get32(in + 16); b->npos_size = get32(in + 20); b->lengths_size = get32(in + 24);
+        b->original_seq_size = get32(in + 28); b->original_qual_size = get32(in + 32);
+        return 36;
+    }
+    return FQZ_E_BLOCK_VERSION;
+}
+
+// ===========================================================================
+// bounds
+// ===========================================================================
+extern "C" size_t fqz_entropy_bound(size_t n)
+{
+    if (!n) return 0;
+    return 10 + n + 3 * ((n + FQZ_CHUNK - 1) / FQZ_CHUNK);
+}
+
+extern "C" size_t fqz_encode_bound(size_t n_bytes)
+{
+    // pre-entropy bytes <= 2*text + small per-record terms (each record has >= 4 text bytes),
+    // every chunk stored raw, plus block and frame headers
+    return 2 * n_bytes + (n_bytes / 1024 + 64) * 128 + 4096;
+}
+
+// ===========================================================================
+// device-resident batches
+// ===========================================================================
+static hipStream_t pick_stream(fqz_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+extern "C" int fqz_encode_batch_launch(fqz_ctx *ctx, const uint8_t *d_fastq, size_t n_bytes, uint32_t records_per_block, int qual_encoding,
+                                       uint32_t flags, uint8_t *d_out, size_t out_cap, void *stream)
+{
+    if (!ctx || (!d_fastq && n_bytes) || !d_out) return FQZ_E_ARG;
+    return fqz_enc_launch(ctx, d_fastq, n_bytes, records_per_block, qual_encoding, flags, d_out, out_cap, pick_stream(ctx, stream));
+}
+
+extern "C" int fqz_encode_batch_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uint64_t *block_len, size_t max_blocks)
+{
+    if (!ctx) return FQZ_E_ARG;
+    return fqz_enc_finish(ctx, res, block_off, block_len, max_blocks);
+}
+
+extern "C" int fqz_encode_batch_dev(fqz_ctx *ctx, const uint8_t *d_fastq, size_t n_bytes, uint32_t records_per_block, int qual_encoding,
+                                    uint32_t flags, uint8_t *d_out, size_t out_cap, fqz_batch_result *res, uint64_t *block_off,
+                                    uint64_t *block_len, size_t max_blocks, void *stream)
+{
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int rc = fqz_encode_batch_launch(ctx, d_fastq, n_bytes, records_per_block, qual_encoding, flags, d_out, out_cap, stream);
+        if (rc) return rc;
+        rc = fqz_encode_batch_finish(ctx, res, block_off, block_len, max_blocks);
+        // more lines than the optimistic line-table capacity: finish() recorded the exact need; run again
+        if (rc == FQZ_E_TOO_LARGE && attempt == 0) continue;
+        return rc;
+    }
+    return FQZ_E_TOO_LARGE;
+}
+
+extern "C" int fqz_decode_batch_launch(fqz_ctx *ctx, const uint8_t *d_blocks, size_t n_bytes, uint8_t version, int qual_encoding,
+                                       uint8_t *d_out, size_t out_cap, void *stream)
+{
+    if (!ctx || (!d_blocks && n_bytes)) return FQZ_E_ARG;
+    return fqz_dec_launch(ctx, d_blocks, n_bytes, version, qual_encoding, d_out, out_cap, pick_stream(ctx, stream));
+}
+extern "C" int fqz_decode_batch_finish(fqz_ctx *ctx, fqz_batch_result *res)
+{
+    if (!ctx) return FQZ_E_ARG;
+    return fqz_dec_finish(ctx, res);
+}
+extern "C" int fqz_decode_batch_dev(fqz_ctx *ctx, const uint8_t *d_blocks, size_t n_bytes, uint8_t version, int qual_encoding,
+                                    uint8_t *d_out, size_t out_cap, fqz_batch_result *res, void *stream)
+{
+    int rc = fqz_decode_batch_launch(ctx, d_blocks, n_bytes, version, qual_encoding, d_out, out_cap, stream);
+    if (rc) return rc;
+    return fqz_decode_batch_finish(ctx, res);
+}
+
+extern "C" int fqz_debug_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_t stream_len[6])
+{
+    if (!ctx || !stream_len) return FQZ_E_ARG;
+    return fqz_enc_get_streams(ctx, block, streams, stream_len);
+}
+
+// ===========================================================================
+// host-buffer entry points: H2D -> device pipeline -> D2H
+// ===========================================================================
+static int stage_in(fqz_ctx *ctx, const uint8_t *src, size_t n)
+{
+    int rc = ctx->d_in.ensure(n + 64);
+    if (rc) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(ctx->d_in.p, src, n, hipMemcpyHostToDevice, ctx->stream));
+    return FQZ_OK;
+}
+
+// Encodes `n` bytes of FASTQ (whole records) as blocks of rpb records into ctx->d_out.
+static int encode_staged(fqz_ctx *ctx, const uint8_t *fastq, size_t n, uint32_t rpb, int qual_encoding, uint32_t flags,
+                         fqz_batch_result *res, std::vector<uint64_t> *offs, std::vector<uint64_t> *lens)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = stage_in(ctx, fastq, n);
+    if (rc) return rc;
+    size_t cap = fqz_encode_bound(n);
+    if ((rc = ctx->d_out.ensure(cap + 64))) return rc;
+    size_t max_blocks = n / 4 / (rpb ? rpb : 1) + 2;
+    if (offs) { offs->assign(max_blocks, 0); lens->assign(max_blocks, 0); }
+    return fqz_encode_batch_dev(ctx, ctx->d_in.as<uint8_t>(), n, rpb, qual_encoding, flags, ctx->d_out.as<uint8_t>(), cap, res,
+                                offs ? offs->data() : nullptr, lens ? lens->data() : nullptr, max_blocks, ctx->stream);
+}
+
+extern "C" int fqz_encode_block(fqz_ctx *ctx, const uint8_t *fastq, size_t n_bytes, int qual_encoding, uint8_t *out, size_t out_cap,
+                                size_t *out_len, uint32_t *n_records)
+{
+    if (!ctx || (!fastq && n_bytes) || !out || !out_len) return FQZ_E_ARG;
+    *out_len = 0;
+    fqz_batch_result res;
+    // one block, whatever its record count: rpb = max so that everything lands in block 0
+    int rc = encode_staged(ctx, fastq, n_bytes, 0x7FFFFFFFu, qual_encoding, FQZ_BATCH_FINAL, &res, nullptr, nullptr);
+    if (rc) return rc;
+    if (n_records) *n_records = res.n_records;
+    if (res.out_len > out_cap) return FQZ_E_DST_SMALL;
+    if (res.out_len) HIP_TRY(hipMemcpy(out, ctx->d_out.p, res.out_len, hipMemcpyDeviceToHost));
+    *out_len = res.out_len;
+    return FQZ_OK;
+}
+
+static int decode_staged(fqz_ctx *ctx, const uint8_t *blocks, size_t n, uint8_t version, int qual_encoding, uint8_t *out, size_t out_cap,
+                         size_t *out_len, bool size_only)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = stage_in(ctx, blocks, n);
+    if (rc) return rc;
+    // FASTQ text is bounded by the pre-entropy sizes announced in the frames; the decoder sizes its own
+    // staging buffer and reports the exact length
+    fqz_batch_result res;
+    rc = fqz_dec_launch(ctx, ctx->d_in.as<uint8_t>(), n, version, qual_encoding, nullptr, 0, ctx->stream);
+    if (rc) return rc;
+    rc = fqz_dec_finish(ctx, &res);
+    if (rc) return rc;
+    *out_len = res.out_len;
+    if (size_only) return FQZ_OK;
+    if (res.out_len > out_cap) return FQZ_E_DST_SMALL;
+    if (res.out_len) HIP_TRY(hipMemcpy(out, ctx->d_out.p, res.out_len, hipMemcpyDeviceToHost));
+    return FQZ_OK;
+}
+
+extern "C" int fqz_decode_block(fqz_ctx *ctx, const uint8_t *block, size_t n, uint8_t version, int qual_encoding, uint8_t *out,
+                                size_t out_cap, size_t *out_len)
+{
+    if (!ctx || !block || !out_len) return FQZ_E_ARG;
+    return decode_staged(ctx, block, n, version, qual_encoding, out, out_cap, out_len, false);
+}
+
+extern "C" int fqz_decode_block_size(fqz_ctx *ctx, const uint8_t *block, size_t n, uint8_t version, size_t *out_len)
+{
+    if (!ctx || !block || !out_len) return FQZ_E_ARG;
+    return decode_staged(ctx, block, n, version, FQZ_ENCODING_PHRED33, nullptr, 0, out_len, true);
+}
+
+// ===========================================================================
+// compress.Compress / compress.Decompress on memory buffers
+// ===========================================================================
+// Largest slice of FASTQ text handed to one device pass.
+static const size_t FQZ_HOST_BATCH = 512ull << 20;
+
+extern "C" int fqz_compress(fqz_ctx *ctx, const uint8_t *fastq, size_t n, uint8_t *out, size_t out_cap, size_t *out_len,
+                            const fqz_options *opts)
+{
+    if (!ctx || (!fastq && n) || !out || !out_len) return FQZ_E_ARG;
+    *out_len = 0;
+    fqz_options o = {FQZ_DEFAULT_BLOCK_SIZE, 0};                       // compress.go:126-128 (nil opts)
+    if (opts) o = *opts;
+    if (!o.block_size) o.block_size = FQZ_DEFAULT_BLOCK_SIZE;          // compress.go:129-131
+    const uint32_t rpb = FQZ_DEFAULT_BLOCK_SIZE;                       // batches are always 100 000 records (compress.go:48-52, App. B-4)
+    if (out_cap < FQZ_FILE_HEADER_SIZE) return FQZ_E_DST_SMALL;
+    size_t w = FQZ_FILE_HEADER_SIZE, pos = 0;
+    int enc = FQZ_DETECT_ENCODING;                                      // decided on the first batch (compress.go:146-154)
+    bool first = true;
+    uint8_t flags = 0;
+    while (first || pos < n) {
+        size_t take = n - pos < FQZ_HOST_BATCH ? n - pos : FQZ_HOST_BATCH;
+        bool final_batch = pos + take == n;
+        fqz_batch_result res;
+        int rc = encode_staged(ctx, fastq + pos, take, rpb, enc, final_batch ? FQZ_BATCH_FINAL : 0, &res, nullptr, nullptr);
+        if (rc) return rc;                                              // "parsing FASTQ: ..." / "compressing block: ..."
+        if (first) {
+            enc = res.qual_encoding;
+            if (enc == FQZ_ENCODING_PHRED64) flags |= FQZ_FLAG_PHRED64; // compress.go:162-164
+            first = false;
+        }
+        if (!final_batch && res.consumed == 0) {
+            // less than one whole block in this slice: widen it (or finish if it already is everything)
+            return FQZ_E_TOO_LARGE;
+        }
+        if (w + res.out_len > out_cap) return FQZ_E_DST_SMALL;
+        if (res.out_len) HIP_TRY(hipMemcpy(out + w, ctx->d_out.p, res.out_len, hipMemcpyDeviceToHost));
+        w += res.out_len;
+        pos += final_batch ? take : res.consumed;
+        if (final_batch) break;
+    }
+    fqz_file_header fh = {FQZ_VERSION2, o.block_size, flags};          // compress.go:157-161
+    fqz_write_file_header(&fh, out);
+    *out_len = w;
+    return FQZ_OK;
+}
+
+extern "C" int fqz_decompress(fqz_ctx *ctx, const uint8_t *fqz, size_t n, uint8_t *out, size_t out_cap, size_t *out_len,
+                              const fqz_decompress_options *opts)
+{
+    (void)opts;
+    if (!ctx || !fqz || !out_len) return FQZ_E_ARG;
+    *out_len = 0;
+    fqz_file_header fh;
+    int rc = fqz_read_file_header(fqz, n, &fh);                         // compress.go:567-570
+    if (rc) return rc;
+    if (fh.version != FQZ_VERSION1 && fh.version != FQZ_VERSION2) return FQZ_E_FILE_VERSION; // compress.go:571-573
+    int enc = (fh.flags & FQZ_FLAG_PHRED64) ? FQZ_ENCODING_PHRED64 : FQZ_ENCODING_PHRED33;    // compress.go:576-579
+    // walk the block headers (readNextDecompressJob, compress.go:721-758) and cut slices of whole blocks
+    size_t pos = FQZ_FILE_HEADER_SIZE, w = 0;
+    while (pos < n) {
+        size_t start = pos, slice = 0;
+        while (pos < n) {
+            fqz_block_header bh;
+            int hs = fqz_read_block_header(fqz + pos, n - pos, fh.version, &bh);
+            if (hs < 0) return hs;                                      // "reading block header: unexpected EOF"
+            unsigned long long payload = (unsigned long long)bh.seq_size + bh.qual_size + bh.header_size + bh.plus_size +
+                                         bh.npos_size + bh.lengths_size;
+            if (payload > n - pos - (size_t)hs) return FQZ_E_READ_DATA; // compress.go:732
+            size_t blk = (size_t)hs + (size_t)payload;
+            if (slice && slice + blk > FQZ_HOST_BATCH / 2) break;
+            slice += blk;
+            pos += blk;
+        }
+        size_t got = 0;
+        rc = decode_staged(ctx, fqz + start, slice, fh.version, enc, out ? out + w : nullptr, out ? out_cap - w : 0, &got, out == nullptr);
+        if (rc) return rc;
+        w += got;
+    }
+    *out_len = w;
+    return FQZ_OK;
+}
+
+// ---- file forms (cmd/fqpack/main.go:190-203 execute) -----------------------------------
+static int read_file(const char *path, std::vector<uint8_t> &buf)
+{
+    FILE *f = strcmp(path, "-") ? fopen(path, "rb") : stdin;
+    if (!f) return FQZ_E_IO;
+    size_t cap = 1 << 20, n = 0;
+    buf.resize(cap);
+    for (;;) {
+        if (n == cap) { cap *= 2; buf.resize(cap); }
+        size_t r = fread(buf.data() + n, 1, cap - n, f);
+        n += r;
+        if (r == 0) break;
+    }
+    int err = ferror(f);
+    if (f != stdin) fclose(f);
+    buf.resize(n);
+    return err ? FQZ_E_IO : FQZ_OK;
+}
+static int write_file(const char *path, const uint8_t *p, size_t n)
+{
+    FILE *f = strcmp(path, "-") ? fopen(path, "wb") : stdout;
+    if (!f) return FQZ_E_IO;
+    size_t w = n ? fwrite(p, 1, n, f) : 0;
+    int bad = (w != n) || fflush(f);
+    if (f != stdout) bad |= fclose(f);
+    return bad ? FQZ_E_IO : FQZ_OK;
+}
+
+extern "C" int fqz_compress_file(fqz_ctx *ctx, const char *in_path, const char *out_path, const fqz_options *opts)
+{
+    if (!ctx || !in_path || !out_path) return FQZ_E_ARG;
+    std::vector<uint8_t> in, out;
+    int rc = read_file(in_path, in);
+    if (rc) return rc;
+    out.resize(fqz_encode_bound(in.size()) + FQZ_FILE_HEADER_SIZE);
+    size_t n = 0;
+    rc = fqz_compress(ctx, in.data(), in.size(), out.data(), out.size(), &n, opts);
+    if (rc) return rc;
+    return write_file(out_path, out.data(), n);
+}
+
+extern "C" int fqz_decompress_file(fqz_ctx *ctx, const char *in_path, const char *out_path, const fqz_decompress_options *opts)
+{
+    if (!ctx || !in_path || !out_path) return FQZ_E_ARG;
+    std::vector<uint8_t> in, out;
+    int rc = read_file(in_path, in);
+    if (rc) return rc;
+    size_t n = 0;
+    rc = fqz_decompress(ctx, in.data(), in.size(), nullptr, 0, &n, opts);
+    if (rc) return rc;
+    out.resize(n ? n : 1);
+    rc = fqz_decompress(ctx, in.data(), in.size(), out.data(), n, &n, opts);
+    if (rc) return rc;
+    return write_file(out_path, out.data(), n);
+}
+
+// ===========================================================================
+// internal/encoder primitive mirrors: small kernels built from the same device helpers
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_prim_pack(const uint8_t *seq, uint32_t n, uint8_t *packed, uint16_t *npos, uint32_t *n_npos)
+{
+    // sequence.go:139-184; single workgroup, positions kept ascending through a running ballot offset
+    __shared__ uint32_t sh[4];
+    __shared__ uint32_t run;
+    if (threadIdx.x == 0) run = 0;
+    __syncthreads();
+    uint32_t nq = (n + 3) >> 2;
+    for (uint32_t base = 0; base < nq; base += 256) {
+        uint32_t i = base + threadIdx.x, inv = 0, cnt = 0;
+        if (i < nq) {
+            uint32_t have = n - 4 * i < 4 ? n - 4 * i : 4, x = 0;
+            for (uint32_t j = 0; j < have; j++) x |= (uint32_t)seq[4 * i + j] << (8 * j);
+            uint32_t valid = acgt_mask(x);
+            uint32_t in_read = have < 4 ? 0x80808080u >> (8 * (4 - have)) : 0x80808080u;
+            packed[i] = (uint8_t)pack4(x, valid);
+            inv = ~valid & in_read;
+            for (uint32_t j = 0; j < 4; j++) if ((inv & (0x80u << (8 * j))) && 4 * i + j < FQZ_MAX_SEQUENCE_LENGTH) cnt++;
+        }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan_256(cnt, sh, &tot) + run;
+        for (uint32_t j = 0; j < 4; j++)
+            if ((inv & (0x80u << (8 * j))) && 4 * i + j < FQZ_MAX_SEQUENCE_LENGTH) npos[ex++] = (uint16_t)(4 * i + j);
+        __syncthreads();
+        if (threadIdx.x == 0) run += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_npos = run;
+}
+
+__global__ __launch_bounds__(256) void k_prim_unpack(const uint8_t *packed, const uint16_t *npos, uint32_t n_npos, uint32_t seq_len,
+                                                     uint8_t *seq, int *err)
+{
+    // sequence.go:188-223
+    for (uint32_t i = threadIdx.x; i < seq_len; i += 256) {
+        uint32_t c = (packed[i >> 2] >> ((i & 3) << 1)) & 3;
+        seq[i] = (uint8_t)((0x54474341u >> (8 * c)) & 0xFF); // "ACGT"
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_npos; k += 256) {
+        if (npos[k] >= seq_len) *err = 1; else seq[npos[k]] = 'N';
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prim_add(uint8_t *q, uint32_t n, uint32_t delta)
+{
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) q[i] = (uint8_t)(q[i] + delta);
+}
+
+__global__ __launch_bounds__(256) void k_prim_delta_enc(const uint8_t *in, uint8_t *out, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = (uint8_t)(in[i] - (i ? in[i - 1] : 0));
+}
+
+__global__ __launch_bounds__(256) void k_prim_delta_dec(uint8_t *q, uint32_t n)
+{
+    // quality.go:107-118: inclusive prefix sum mod 256; single workgroup, carry across strips
+    __shared__ uint32_t sh[4];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < n ? q[i] : 0, tot;
+        uint32_t ex = block_excl_scan_256(v, sh, &tot);
+        if (i < n) q[i] = (uint8_t)(carry + ex + v);
+        carry += tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prim_min(const uint8_t *q, uint32_t n, uint32_t *mn)
+{
+    uint32_t m = 255;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = q[i] < m ? q[i] : m;
+    m = wave_min(m);
+    if ((threadIdx.x & 63) == 0) atomicMin(mn, m);
+}
+
+struct Scratch { // small RAII device scratch for the primitive calls
+    void *p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : FQZ_E_NOMEM; }
+};
+
+extern "C" int fqz_pack_bases(fqz_ctx *ctx, const uint8_t *seq, size_t n, uint8_t *packed, uint16_t *npos, size_t *n_npos)
+{
+    if (!ctx || (!seq && n) || n > 0x7FFFFFFFu || !n_npos) return FQZ_E_ARG;
+    *n_npos = 0;
+    if (!n) return FQZ_OK; // sequence.go:141-143
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t pl = (n + 3) / 4, lim = n < FQZ_MAX_SEQUENCE_LENGTH ? n : FQZ_MAX_SEQUENCE_LENGTH;
+    Scratch s;
+    size_t o_p = fqz_align_up(n, 16), o_n = o_p + fqz_align_up(pl, 16), o_c = o_n + fqz_align_up(2 * lim, 16);
+    if (s.alloc(o_c + 16)) return FQZ_E_NOMEM;
+    uint8_t *d = (uint8_t *)s.p;
+    HIP_TRY(hipMemcpyAsync(d, seq, n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_prim_pack, dim3(1), dim3(256), 0, ctx->stream, d, (uint32_t)n, d + o_p, (uint16_t *)(d + o_n), (uint32_t *)(d + o_c));
+    uint32_t cnt = 0;
+    HIP_TRY(hipMemcpyAsync(&cnt, d + o_c, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(packed, d + o_p, pl, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (cnt && npos) HIP_TRY(hipMemcpy(npos, d + o_n, 2ull * cnt, hipMemcpyDeviceToHost));
+    *n_npos = cnt;
+    return FQZ_OK;
+}
+
+extern "C" int fqz_unpack_bases(fqz_ctx *ctx, const uint8_t *packed, const uint16_t *npos, size_t n_npos, size_t seq_len, uint8_t *seq)
+{
+    if (!ctx || seq_len > 0x7FFFFFFFu || (seq_len && (!packed || !seq)) || (n_npos && !npos)) return FQZ_E_ARG;
+    if (!seq_len) return FQZ_OK; // sequence.go:189-191
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t pl = (seq_len + 3) / 4;
+    Scratch s;
+    size_t o_n = fqz_align_up(pl, 16), o_s = o_n + fqz_align_up(2 * n_npos, 16), o_e = o_s + fqz_align_up(seq_len, 16);
+    if (s.alloc(o_e + 16)) return FQZ_E_NOMEM;
+    uint8_t *d = (uint8_t *)s.p;
+    HIP_TRY(hipMemcpyAsync(d, packed, pl, hipMemcpyHostToDevice, ctx->stream));
+    if (n_npos) HIP_TRY(hipMemcpyAsync(d + o_n, npos, 2 * n_npos, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d + o_e, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_prim_unpack, dim3(1), dim3(256), 0, ctx->stream, d, (const uint16_t *)(d + o_n), (uint32_t)n_npos, (uint32_t)seq_len,
+                       d + o_s, (int *)(d + o_e));
+    int err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, d + o_e, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(seq, d + o_s, seq_len, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return err ? FQZ_E_NPOS_RANGE : FQZ_OK;
+}
+
+extern "C" int fqz_detect_encoding(fqz_ctx *ctx, const uint8_t *quals, const uint64_t *offsets, size_t n, int *encoding)
+{
+    if (!ctx || !encoding || (n && !offsets)) return FQZ_E_ARG;
+    *encoding = FQZ_ENCODING_PHRED33;
+    size_t total = n ? (size_t)(offsets[n] - offsets[0]) : 0;
+    if (!total) return FQZ_OK; // quality.go:36-39
+    if (total > 0x7FFFFFFFu) return FQZ_E_TOO_LARGE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Scratch s;
+    size_t o_m = fqz_align_up(total, 16);
+    if (s.alloc(o_m + 16)) return FQZ_E_NOMEM;
+    uint8_t *d = (uint8_t *)s.p;
+    HIP_TRY(hipMemcpyAsync(d, quals + offsets[0], total, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d + o_m, 0xFF, 4, ctx->stream));
+    uint32_t grid = (uint32_t)((total + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_prim_min, dim3(grid), dim3(256), 0, ctx->stream, d, (uint32_t)total, (uint32_t *)(d + o_m));
+    uint32_t mn = 255;
+    HIP_TRY(hipMemcpyAsync(&mn, d + o_m, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    mn &= 0xFF; // quality.go:43-48
+    *encoding = (mn >= 64 && mn != 255) ? FQZ_ENCODING_PHRED64 : FQZ_ENCODING_PHRED33;
+    return FQZ_OK;
+}
+
+static int prim_inplace(fqz_ctx *ctx, uint8_t *q, size_t n, int which, uint32_t arg)
+{
+    if (!ctx || (!q && n) || n > 0x7FFFFFFFu) return FQZ_E_ARG;
+    if (!n) return FQZ_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Scratch s;
+    size_t o_b = fqz_align_up(n, 16);
+    if (s.alloc(2 * o_b + 16)) return FQZ_E_NOMEM;
+    uint8_t *d = (uint8_t *)s.p;
+    HIP_TRY(hipMemcpyAsync(d, q, n, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t grid = (uint32_t)((n + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    uint8_t *res = d;
+    if (which == 0) hipLaunchKernelGGL(k_prim_add, dim3(grid), dim3(256), 0, ctx->stream, d, (uint32_t)n, arg);
+    else if (which == 1) { hipLaunchKernelGGL(k_prim_delta_enc, dim3(grid), dim3(256), 0, ctx->stream, d, d + o_b, (uint32_t)n); res = d + o_b; }
+    else hipLaunchKernelGGL(k_prim_delta_dec, dim3(1), dim3(256), 0, ctx->stream, d, (uint32_t)n);
+    HIP_TRY(hipMemcpyAsync(q, res, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FQZ_OK;
+}
+
+extern "C" int fqz_normalize_quality(fqz_ctx *ctx, uint8_t *q, size_t n, int enc)
+{
+    return prim_inplace(ctx, q, n, 0, 256u - (enc == FQZ_ENCODING_PHRED64 ? 64u : 33u));
+}
+extern "C" int fqz_denormalize_quality(fqz_ctx *ctx, uint8_t *q, size_t n, int enc)
+{
+    return prim_inplace(ctx, q, n, 0, enc == FQZ_ENCODING_PHRED64 ? 64u : 33u);
+}
+extern "C" int fqz_delta_encode(fqz_ctx *ctx, uint8_t *q, size_t n) { return prim_inplace(ctx, q, n, 1, 0); }
+extern "C" int fqz_delta_decode(fqz_ctx *ctx, uint8_t *q, size_t n) { return prim_inplace(ctx, q, n, 2, 0); }
+
+// ===========================================================================
+// entropy stage alone
+// ===========================================================================
+int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, size_t *out_len, hipStream_t st);
+int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, size_t *out_len, hipStream_t st);
+
+extern "C" int fqz_entropy_encode(fqz_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len)
+{
+    if (!ctx || (!src && n) || !out_len) return FQZ_E_ARG;
+    *out_len = 0;
+    if (!n) return FQZ_OK; // empty stream -> 0-byte payload
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = stage_in(ctx, src, n);
+    if (rc) return rc;
+    size_t bound = fqz_entropy_bound(n);
+    if ((rc = ctx->d_out.ensure(bound + 64))) return rc;
+    size_t got = 0;
+    rc = fqz_enc_entropy_only(ctx, ctx->d_in.as<uint8_t>(), n, ctx->d_out.as<uint8_t>(), bound, &got, ctx->stream);
+    if (rc) return rc;
+    if (got > cap) return FQZ_E_DST_SMALL;
+    HIP_TRY(hipMemcpy(dst, ctx->d_out.p, got, hipMemcpyDeviceToHost));
+    *out_len = got;
+    return FQZ_OK;
+}
+
+extern "C" int fqz_entropy_decode(fqz_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len)
+{
+    if (!ctx || (!src && n) || !out_len) return FQZ_E_ARG;
+    *out_len = 0;
+    if (!n) return FQZ_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = stage_in(ctx, src, n);
+    if (rc) return rc;
+    if ((rc = ctx->d_out.ensure(cap + 64))) return rc;
+    size_t got = 0;
+    rc = fqz_dec_entropy_only(ctx, ctx->d_in.as<uint8_t>(), n, ctx->d_out.as<uint8_t>(), cap, &got, ctx->stream);
+    if (rc) return rc;
+    if (got) HIP_TRY(hipMemcpy(dst, ctx->d_out.p, got, hipMemcpyDeviceToHost));
+    *out_len = got;
+    return FQZ_OK;
+}
+
+// ===========================================================================
+// synthetic FASTQ — host generator for bench / tests
+// ===========================================================================
+static inline uint64_t splitmix64(uint64_t &s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct Xoshiro {
+    uint64_t s[4];
+    static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    void seed(uint64_t v) { for (int i = 0; i < 4; i++) s[i] = splitmix64(v); }
+    inline uint64_t next()
+    {
+        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    inline uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
+};
+
+static inline uint8_t *put_dec(uint8_t *p, uint64_t v)
+{
+    char tmp[24];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) *p++ = (uint8_t)tmp[--k];
+    return p;
+}
+
+extern "C" int fqz_synth_fastq(const fqz_synth_params *pp, uint64_t n_records, uint8_t *out, size_t cap, size_t *out_len, uint64_t *n_written)
+{
+    if (!pp || !out || !out_len) return FQZ_E_ARG;
+    fqz_synth_params p = *pp;
+    if (!p.min_len && !p.max_len) p.min_len = p.max_len = 150;
+    if (p.max_len < p.min_len) return FQZ_E_ARG;
+    if (p.phred != 33 && p.phred != 64) p.phred = 33;
+    const size_t worst = 2ull * p.max_len + 160;
+    uint8_t *w = out, *end = out + cap;
+    uint64_t r = 0;
+    static const uint8_t lv4[4] = {37, 25, 11, 2}; // F : , #  (Phred+33)
+    for (; r < n_records; r++) {
+        if ((size_t)(end - w) < worst) break;
+        uint64_t i = p.first_record + r;
+        Xoshiro g;
+        g.seed(p.seed * 0x9E3779B97F4A7C15ull + i); // per-record stream: shards generate identical records independently
+        uint32_t L = p.min_len + (p.max_len > p.min_len ? g.below(p.max_len - p.min_len + 1) : 0);
+        *w++ = '@';
+        memcpy(w, "SIM:1:FCX123:1:", 15); w += 15;
+        w = put_dec(w, 1101 + i / 200000); *w++ = ':';
+        w = put_dec(w, 1000 + (7919 * i) % 20000); *w++ = ':';
+        w = put_dec(w, 1000 + (104729 * i) % 20000);
+        memcpy(w, " 1:N:0:ATCACG", 13); w += 13;
+        if (p.max_len != p.min_len) { memcpy(w, " length=", 8); w += 8; w = put_dec(w, L); }
+        *w++ = '\n';
+        // bases: uniform ACGT, N in geometric runs (mean 3) with overall fraction n_permille/1000
+        uint32_t nrun = 0;
+        for (uint32_t j = 0; j < L;) {
+            uint64_t x = g.next();
+            for (int k = 0; k < 16 && j < L; k++, j++, x >>= 4) {
+                uint8_t b = "ACGT"[x & 3];
+                if (p.n_permille) { // a run of 1..5 N (mean 3) starts with probability permille/3000
+                    if (nrun) { b = 'N'; nrun--; }
+                    else if (g.below(3000) < p.n_permille) { b = 'N'; nrun = g.below(5); }
+                }
+                *w++ = b;
+            }
+        }
+        *w++ = '\n'; *w++ = '+'; *w++ = '\n';
+        if (p.quality_profile == 0) {
+            // 4-level binned Markov chain: stay 0.93; from F: ':' 0.05, ',' 0.015, '#' 0.005; back to F with 0.5
+            uint32_t cur = 0;
+            for (uint32_t j = 0; j < L; j++) {
+                uint32_t u = g.below(1000);
+                if (u >= 930) {
+                    if (cur == 0) cur = u < 980 ? 1 : (u < 995 ? 2 : 3);
+                    else cur = (u & 1) ? 0 : 1 + g.below(3);
+                }
+                *w++ = (uint8_t)(lv4[cur] + p.phred);
+            }
+        } else {
+            // 41-level HiSeq-like random walk: start 34 +- 4, steps -2..+1 weighted to slow decay, floor 2, cap 40
+            int q = 30 + (int)g.below(9);
+            for (uint32_t j = 0; j < L; j++) {
+                uint32_t u = g.below(100);
+                q += u < 8 ? -2 : (u < 30 ? -1 : (u < 80 ? 0 : 1));
+                if (q < 2) q = 2;
+                if (q > 40) q = 40;
+                *w++ = (uint8_t)(q + (int)p.phred);
+            }
+        }
+        *w++ = '\n';
+    }
+    *out_len = (size_t)(w - out);
+    if (n_written) *n_written = r;
+    return FQZ_OK;
+}

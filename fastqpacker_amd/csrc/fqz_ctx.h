@@ -1,0 +1,111 @@
+// fqz_ctx.h — the context object behind the opaque fqz_ctx of include/fqz.h.
+#pragma once
+#include "fqz_internal.h"
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return FQZ_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = fqz_align_up(bytes + bytes / 8, 1 << 20);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fqz_set_hip_error(e, "hipMalloc(workspace)");
+        cap = want;
+        return FQZ_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return FQZ_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = fqz_align_up(bytes + bytes / 8, 1 << 16);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fqz_set_hip_error(e, "hipHostMalloc");
+        cap = want;
+        return FQZ_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct EncState {
+    // inputs of the batch in flight
+    const uint8_t *d_text = nullptr;
+    size_t n_bytes = 0;
+    uint32_t rpb = 0;
+    uint32_t flags = 0;
+    uint8_t *d_out = nullptr;
+    size_t out_cap = 0;
+    hipStream_t stream = nullptr;
+    bool in_flight = false;
+    // capacities
+    uint32_t n_tiles = 0, line_cap = 0, rec_cap = 0, block_cap = 0, chunk_cap = 0;
+    size_t arena_cap = 0, npos_cap = 0;
+    // device workspaces
+    DevBuf info;      // EncInfo
+    DevBuf tile_cnt;  // u32[n_tiles+1]
+    DevBuf ls;        // u32[line_cap+1] line starts
+    DevBuf E;         // u32[5][rec_cap+1]: seq, qual, hdr, plus, npos sizes -> exclusive offsets
+    DevBuf plans;     // BlockPlan[block_cap]
+    DevBuf arena;     // seq/qual/hdr/plus/len pre-entropy streams
+    DevBuf npos;      // nPos pre-entropy streams
+    DevBuf slots;     // chunk_cap * FQZ_SLOT
+    DevBuf csize;     // u32[chunk_cap+1] -> exclusive prefix
+    DevBuf partials;  // scan partial sums
+    PinnedBuf h_info; // EncInfo
+    PinnedBuf h_plans;
+};
+
+struct DecState {
+    const uint8_t *d_in = nullptr;
+    size_t n_bytes = 0;
+    uint8_t *d_out = nullptr;
+    size_t out_cap = 0;
+    hipStream_t stream = nullptr;
+    bool in_flight = false;
+    DevBuf info, blocks, chunks, streams, rec, partials, tables;
+    PinnedBuf h_info, h_blocks;
+    uint32_t n_blocks = 0;
+};
+
+struct fqz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    EncState enc;
+    DecState dec;
+    // staging for the host-buffer entry points
+    DevBuf d_in, d_out;
+    PinnedBuf h_stage;
+};
+
+// fqz_encode.hip
+int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags,
+                   uint8_t *d_out, size_t out_cap, hipStream_t stream);
+int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uint64_t *block_len, size_t max_blocks);
+int fqz_enc_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_t stream_len[6]);
+// fqz_decode.hip
+int fqz_dec_launch(fqz_ctx *ctx, const uint8_t *d_blocks, size_t n_bytes, uint8_t version, int qual_encoding, uint8_t *d_out,
+                   size_t out_cap, hipStream_t stream);
+int fqz_dec_finish(fqz_ctx *ctx, fqz_batch_result *res);

@@ -1,0 +1,107 @@
+// fqz_device.h — device-side helpers shared by the encode and decode kernels (gfx950, wave64).
+#pragma once
+#include "fqz_internal.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// 0x80 in every byte of y that is zero (exact per byte, no cross-byte carries)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t y)
+{
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+}
+__device__ __forceinline__ uint32_t count_newlines(uint32_t x) { return __popc(zero_bytes(x ^ 0x0A0A0A0Au)); }
+
+// bytewise x - y (mod 256 per byte)
+__device__ __forceinline__ uint32_t sub_bytes(uint32_t x, uint32_t y)
+{
+    const uint32_t H = 0x80808080u;
+    return ((x | H) - (y & ~H)) ^ ((x ^ ~y) & H);
+}
+// bytewise x + y
+__device__ __forceinline__ uint32_t add_bytes(uint32_t x, uint32_t y)
+{
+    const uint32_t H = 0x80808080u;
+    return ((x & ~H) + (y & ~H)) ^ ((x ^ y) & H);
+}
+
+// 0x80 in every byte of x that is one of ACGTacgt.  u = x|0x20 folds case; the
+// low 3 bits of a/c/g/t (1,3,7,4) index an 8-entry byte table through v_perm.
+__device__ __forceinline__ uint32_t acgt_mask(uint32_t x)
+{
+    uint32_t u = x | 0x20202020u;
+    uint32_t sel = u & 0x07070707u;
+    // table bytes: [0]=0 [1]='a' [2]=0 [3]='c' | [4]='t' [5]=0 [6]=0 [7]='g'
+    uint32_t e = __builtin_amdgcn_perm(0x67000074u, 0x63006100u, sel);
+    return zero_bytes(e ^ u);
+}
+// 2-bit codes (A0 C1 G2 T3) of 4 ASCII bases packed into one byte; non-ACGT -> 0
+__device__ __forceinline__ uint32_t pack4(uint32_t x, uint32_t valid80)
+{
+    uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    uint32_t keep = (valid80 >> 7) | (valid80 >> 6);
+    c &= keep;
+    uint32_t p = c | (c >> 6);
+    p |= p >> 12;
+    return p & 0xFFu;
+}
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    uint32_t l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, WAVE);
+        if (l >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) { uint32_t t = __shfl_xor(v, d, WAVE); v = t < v ? t : v; }
+    return v;
+}
+
+// Exclusive scan of one value per thread over a 256-thread workgroup.
+// sh must hold 4 uint32_t.  Returns the exclusive prefix; *total the sum.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *sh, uint32_t *total)
+{
+    uint32_t incl = wave_incl_scan(v);
+    uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 63) sh[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        uint32_t s = sh[k];
+        if (k < w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+__device__ __forceinline__ int highbit32_d(uint32_t v) { return 31 - __clz(v); }
+
+__device__ __forceinline__ void report_error(EncInfo *info, uint32_t rec, uint32_t order, int code)
+{
+    unsigned long long key = ((unsigned long long)rec << 8) | ((unsigned long long)order << 5) | (unsigned long long)(-code);
+    atomicMin(&info->error_key, key);
+}

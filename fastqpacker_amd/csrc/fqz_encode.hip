@@ -1,0 +1,1224 @@
+// fqz_encode.hip — device-resident encode pipeline (gfx950 / MI355X).
+//
+// Replaces, for a batch of blocks at once, the reference's
+//   fqparser.nextInto/readLine            internal/fqparser/parser.go:136-243   (k_count_nl, k_line_starts, k_record_meta)
+//   encoder.DetectEncoding                internal/encoder/quality.go:22-49     (k_detect)
+//   compressBlockWithBuffers record loop  internal/compress/compress.go:474-520 (k_split_seq, k_split_rest)
+//     encoder.AppendPackedBases           internal/encoder/sequence.go:139-184
+//     encoder.NormalizeQuality+DeltaEncode internal/encoder/quality.go:53-103
+//   6 x zstd.Encoder.EncodeAll            compress.go:523-528                   (k_entropy: Huffman-literal zstd blocks)
+//   BlockHeader.Write + payload concat    container.go:97-109, compress.go:532-552 (k_layout, k_compact)
+//
+// All integer/byte work, HBM-bound: no MFMA.  One launch sequence handles every
+// block of the batch; no host round trip until the result struct is read back.
+#include "fqz_ctx.h"
+#include "fqz_device.h"
+
+#include <string.h>
+
+// ===========================================================================
+// generic in-place exclusive scan of u32 columns (n may live on the device)
+// ===========================================================================
+#define SCAN_ITEMS 16
+#define SCAN_TILE (256 * SCAN_ITEMS)
+
+__device__ __forceinline__ uint32_t scan_n(const uint32_t *n_ptr, uint32_t n_add) { return (n_ptr ? *n_ptr : 0u) + n_add; }
+
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *data, const uint32_t *n_ptr, uint32_t n_add,
+                                                     uint32_t col_stride, uint32_t *partials, uint32_t pstride)
+{
+    __shared__ uint32_t sh[4];
+    uint32_t n = scan_n(n_ptr, n_add);
+    uint32_t base = blockIdx.x * SCAN_TILE;
+    if (base >= n) return;
+    const uint32_t *col = data + (size_t)blockIdx.y * col_stride;
+    uint32_t i0 = base + threadIdx.x * SCAN_ITEMS, s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { uint32_t i = i0 + k; s += (i < n) ? col[i] : 0u; }
+    uint32_t tot;
+    (void)block_excl_scan_256(s, sh, &tot);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * pstride + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_scan_top(uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t col_stride,
+                                                  uint32_t *partials, uint32_t pstride)
+{
+    __shared__ uint32_t sh[4];
+    uint32_t n = scan_n(n_ptr, n_add);
+    uint32_t nwg = (n + SCAN_TILE - 1) / SCAN_TILE;
+    uint32_t *p = partials + (size_t)blockIdx.x * pstride;
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < nwg; b += 256) {
+        uint32_t i = b + threadIdx.x;
+        uint32_t v = i < nwg ? p[i] : 0u, tot;
+        uint32_t ex = block_excl_scan_256(v, sh, &tot);
+        if (i < nwg) p[i] = carry + ex;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) data[(size_t)blockIdx.x * col_stride + n] = carry; // total after the last element
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t col_stride,
+                                                    const uint32_t *partials, uint32_t pstride)
+{
+    __shared__ uint32_t sh[4];
+    uint32_t n = scan_n(n_ptr, n_add);
+    uint32_t base = blockIdx.x * SCAN_TILE;
+    if (base >= n) return;
+    uint32_t *col = data + (size_t)blockIdx.y * col_stride;
+    uint32_t i0 = base + threadIdx.x * SCAN_ITEMS, v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { uint32_t i = i0 + k; v[k] = (i < n) ? col[i] : 0u; s += v[k]; }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan_256(s, sh, &tot) + partials[(size_t)blockIdx.y * pstride + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { uint32_t i = i0 + k; if (i < n) col[i] = ex; ex += v[k]; }
+}
+
+// data: ncols columns of (cap+1) u32, scanned in place; data[col][n] receives the total
+static void launch_scan(hipStream_t st, uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t n_cap, uint32_t ncols,
+                        uint32_t col_stride, uint32_t *partials, uint32_t pstride)
+{
+    uint32_t nwg = (n_cap + SCAN_TILE - 1) / SCAN_TILE;
+    if (nwg == 0) nwg = 1;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nwg, ncols), dim3(256), 0, st, data, n_ptr, n_add, col_stride, partials, pstride);
+    hipLaunchKernelGGL(k_scan_top, dim3(ncols), dim3(256), 0, st, data, n_ptr, n_add, col_stride, partials, pstride);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nwg, ncols), dim3(256), 0, st, data, n_ptr, n_add, col_stride, partials, pstride);
+}
+
+// ===========================================================================
+// K0 line index (parser.go:209-243 readLine)
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_init(EncInfo *info, int qual_encoding)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        EncInfo z;
+        memset(&z, 0, sizeof z);
+        z.error_key = ~0ull;
+        z.min_qual = 255;
+        z.qual_off = qual_encoding == FQZ_ENCODING_PHRED64 ? 64 : 33;
+        *info = z;
+    }
+}
+
+// 16 text bytes of thread t in tile; bytes at or beyond n read as 0
+__device__ __forceinline__ uint4 load_text16(const uint8_t *text, uint32_t off, uint32_t n)
+{
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (off + 16 <= n) {
+        v = *(const uint4 *)(text + off);
+    } else if (off < n) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; off + k < n; k++) w[k >> 2] |= (uint32_t)text[off + k] << (8 * (k & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_count_nl(const uint8_t *text, uint32_t n, uint32_t *tile_cnt)
+{
+    __shared__ uint32_t sh[4];
+    uint32_t off = blockIdx.x * FQZ_TILE + threadIdx.x * 16;
+    uint4 v = load_text16(text, off, n);
+    uint32_t c = count_newlines(v.x) + count_newlines(v.y) + count_newlines(v.z) + count_newlines(v.w);
+    uint32_t tot;
+    (void)block_excl_scan_256(c, sh, &tot);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_line_starts(const uint8_t *text, uint32_t n, const uint32_t *tile_off, uint32_t *ls,
+                                                     uint32_t line_cap)
+{
+    __shared__ uint32_t sh[4];
+    uint32_t off = blockIdx.x * FQZ_TILE + threadIdx.x * 16;
+    uint4 v = load_text16(text, off, n);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m[4], c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { m[k] = zero_bytes(w[k] ^ 0x0A0A0A0Au); c += __popc(m[k]); }
+    uint32_t tot;
+    uint32_t idx = tile_off[blockIdx.x] + block_excl_scan_256(c, sh, &tot);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ls[0] = 0;
+    if (c) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t mk = m[k];
+            while (mk) {
+                int bit = __ffs(mk) - 1; // 7, 15, 23, 31
+                mk &= mk - 1;
+                uint32_t pos = off + 4 * k + (bit >> 3);
+                idx++;
+                if (idx <= line_cap) ls[idx] = pos + 1; // line idx starts after newline idx-1
+            }
+        }
+    }
+}
+
+// ===========================================================================
+// record table (parser.go:136-183 nextInto) and block plan
+// ===========================================================================
+__global__ void k_setup_records(EncInfo *info, const uint32_t *tile_off, uint32_t n_tiles, const uint32_t *ls, uint32_t line_cap,
+                                uint32_t rec_cap, uint32_t block_cap, uint32_t rpb, uint32_t final_batch, uint32_t n_bytes)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t n_lines = tile_off[n_tiles];
+    info->n_lines = n_lines;
+    if (n_lines > line_cap) { info->status = FQZ_E_TOO_LARGE; info->n_rec = 0; info->n_blocks = 0; return; }
+    uint32_t total = n_lines / 4;
+    uint32_t n_rec = final_batch ? total : (total / rpb) * rpb;
+    uint32_t n_blocks = (n_rec + rpb - 1) / rpb;
+    if (n_rec > rec_cap || n_blocks > block_cap) { info->status = FQZ_E_TOO_LARGE; n_rec = 0; n_blocks = 0; }
+    info->n_rec_total = total;
+    info->n_rec = n_rec;
+    info->n_blocks = n_blocks;
+    info->consumed = final_batch ? n_bytes : ls[4 * n_rec];
+}
+
+// line k of record r: [start, start+len) with the trailing '\r' stripped (parser.go:213-215)
+__device__ __forceinline__ void line_span(const uint8_t *text, const uint32_t *ls, uint32_t line, uint32_t *start, uint32_t *len)
+{
+    uint32_t s = ls[line], e = ls[line + 1] - 1; // e = position of '\n'
+    uint32_t l = e - s;
+    if (l > 0 && text[e - 1] == '\r') l--;
+    *start = s;
+    *len = l;
+}
+
+// one thread per record: validation + per-record stream sizes
+__global__ __launch_bounds__(256) void k_record_meta(const uint8_t *text, const uint32_t *ls, EncInfo *info, uint32_t *E, uint32_t estride,
+                                                     uint32_t final_batch)
+{
+    uint32_t n_rec = info->n_rec;
+    uint32_t n_lines = info->n_lines;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n_rec; r += gridDim.x * blockDim.x) {
+        if (r == n_rec) {
+            // a trailing partial record (final batch only): the lines that exist are still
+            // validated before EOF is hit (parser.go:138-165), then it is dropped (parser.go:196-199)
+            if (final_batch && info->status == 0) {
+                uint32_t have = n_lines - 4 * n_rec; // 0..3 complete lines
+                uint32_t s, l;
+                if (have >= 1) { line_span(text, ls, 4 * r, &s, &l); if (l == 0 || text[s] != '@') report_error(info, r, 0, FQZ_E_HDR_AT); }
+                if (have >= 3) { line_span(text, ls, 4 * r + 2, &s, &l); if (l == 0 || text[s] != '+') report_error(info, r, 1, FQZ_E_SEP_PLUS); }
+            }
+            break;
+        }
+        uint32_t s0, l0, s1, l1, s2, l2, s3, l3;
+        line_span(text, ls, 4 * r, &s0, &l0);
+        line_span(text, ls, 4 * r + 1, &s1, &l1);
+        line_span(text, ls, 4 * r + 2, &s2, &l2);
+        line_span(text, ls, 4 * r + 3, &s3, &l3);
+        if (l0 == 0 || text[s0] != '@') { report_error(info, r, 0, FQZ_E_HDR_AT); l0 = 1; }
+        if (l2 == 0 || text[s2] != '+') { report_error(info, r, 1, FQZ_E_SEP_PLUS); l2 = 1; }
+        if (l1 != l3) report_error(info, r, 2, FQZ_E_LEN_MISMATCH);
+        uint32_t H = l0 - 1, P = l2 - 1;
+        if (H > 65535u || P > 65535u) { report_error(info, r, 3, FQZ_E_FIELD_WRAP); H &= 0xFFFF; P &= 0xFFFF; }
+        E[(size_t)S_SEQ * estride + r] = (l1 + 3) >> 2;
+        E[(size_t)S_QUAL * estride + r] = l1;
+        E[(size_t)S_HDR * estride + r] = 2 + H;
+        E[(size_t)S_PLUS * estride + r] = 2 + P;
+    }
+}
+
+// encoder.DetectEncoding (quality.go:22-49) over the first block: min quality byte
+__global__ __launch_bounds__(256) void k_detect(const uint8_t *text, const uint32_t *ls, EncInfo *info, uint32_t rpb)
+{
+    uint32_t n_rec = info->n_rec < rpb ? info->n_rec : rpb;
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    uint32_t mn = 255;
+    for (uint32_t r = wave; r < n_rec; r += nwaves) {
+        uint32_t s, l;
+        line_span(text, ls, 4 * r + 3, &s, &l);
+        for (uint32_t i = lane; i < l; i += WAVE) { uint32_t b = text[s + i]; mn = b < mn ? b : mn; }
+    }
+    mn = wave_min(mn);
+    if (lane == 0 && mn < 255) atomicMin(&info->min_qual, mn);
+}
+
+__global__ void k_finish_detect(EncInfo *info)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t mn = info->min_qual;
+    // quality.go:36-48: <59 anywhere -> Phred33; none -> Phred33; min>=64 -> Phred64; 59..63 -> Phred33
+    info->qual_off = (mn != 255 && mn >= 64) ? 64 : 33;
+}
+
+// arena layout of the streams whose sizes are known after the first scans
+__global__ void k_plan1(EncInfo *info, const uint32_t *E, uint32_t estride, BlockPlan *plans, uint32_t rpb, size_t arena_cap)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    if (info->error_key != ~0ull && info->status == 0) {
+        info->status = -(int32_t)(info->error_key & 31);
+        info->error_record = (uint32_t)(info->error_key >> 8);
+    }
+    uint32_t n_rec = info->n_rec, n_blocks = info->n_blocks;
+    if (info->status) { info->n_blocks = 0; info->n_rec = 0; return; }
+    unsigned long long a = 0;
+    const int order[5] = {S_SEQ, S_QUAL, S_HDR, S_PLUS, S_LEN};
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        BlockPlan *p = &plans[b];
+        uint32_t r0 = b * rpb, r1 = r0 + rpb < n_rec ? r0 + rpb : n_rec;
+        p->rec0 = r0;
+        p->nrec = r1 - r0;
+        for (int q = 0; q < 5; q++) {
+            int s = order[q];
+            uint32_t len = s == S_LEN ? 4 * (r1 - r0) : E[(size_t)s * estride + r1] - E[(size_t)s * estride + r0];
+            p->len[s] = len;
+            p->a_off[s] = (uint32_t)a;
+            a += (len + 15) & ~15u;
+            info->stream_raw[s] += len;
+        }
+        p->orig_seq = E[(size_t)S_QUAL * estride + r1] - E[(size_t)S_QUAL * estride + r0];
+    }
+    if (a > arena_cap || a > 0xFFFFFFF0ull) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; info->n_rec = 0; return; }
+    info->arena_used = (uint32_t)a;
+}
+
+// nPos arena + chunk table once the N counts are scanned
+__global__ void k_plan2(EncInfo *info, const uint32_t *E, uint32_t estride, BlockPlan *plans, size_t npos_cap, uint32_t chunk_cap)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    if (info->error_key != ~0ull && info->status == 0) {
+        info->status = -(int32_t)(info->error_key & 31);
+        info->error_record = (uint32_t)(info->error_key >> 8);
+        info->n_blocks = 0;
+    }
+    uint32_t n_blocks = info->n_blocks;
+    unsigned long long a = 0;
+    uint32_t chunks = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        BlockPlan *p = &plans[b];
+        uint32_t r0 = p->rec0, r1 = r0 + p->nrec;
+        uint32_t len = E[(size_t)S_NPOS * estride + r1] - E[(size_t)S_NPOS * estride + r0];
+        p->len[S_NPOS] = len;
+        p->a_off[S_NPOS] = (uint32_t)a;
+        a += (len + 15) & ~15u;
+        info->stream_raw[S_NPOS] += len;
+        for (int s = 0; s < FQZ_NS; s++) {
+            p->chunk_base[s] = chunks;
+            chunks += (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
+        }
+    }
+    if (a > npos_cap || chunks > chunk_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; chunks = 0; }
+    info->npos_used = (uint32_t)a;
+    info->n_chunks = chunks;
+}
+
+// ===========================================================================
+// K1/K2 sequence stream: 2-bit pack + N count (sequence.go:139-184)
+// one wave per record; a lane packs 4 bases per step
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_split_seq(const uint8_t *text, const uint32_t *ls, EncInfo *info, uint32_t *E, uint32_t estride,
+                                                   const BlockPlan *plans, uint32_t rpb, uint8_t *arena)
+{
+    uint32_t n_rec = info->n_rec;
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    const uint32_t *Eseq = E + (size_t)S_SEQ * estride, *Equal = E + (size_t)S_QUAL * estride;
+    for (uint32_t r = wave; r < n_rec; r += nwaves) {
+        uint32_t b = r / rpb;
+        const BlockPlan *p = &plans[b];
+        uint32_t L = Equal[r + 1] - Equal[r];
+        const uint8_t *src = text + ls[4 * r + 1];
+        uint8_t *dst = arena + p->a_off[S_SEQ] + (Eseq[r] - Eseq[p->rec0]);
+        uint32_t nn = 0, beyond = 0;
+        for (uint32_t i = lane; 4 * i < L; i += WAVE) {
+            // the sequence line is followed by "\n+...\n<L quality bytes>": a 4-byte read never leaves the text
+            uint32_t x = load_u32_unaligned(src + 4 * i);
+            uint32_t have = L - 4 * i;
+            uint32_t in_read = 0x80808080u;
+            if (have < 4) { x &= (1u << (8 * have)) - 1; in_read >>= 8 * (4 - have); } // bytes past the read pack as 0
+            uint32_t valid = acgt_mask(x);
+            uint32_t invalid = ~valid & in_read;
+            dst[i] = (uint8_t)pack4(x, valid);
+            if (invalid) {
+                if (4 * i + 3 < FQZ_MAX_SEQUENCE_LENGTH) nn += __popc(invalid);
+                else {
+                    for (uint32_t j = 0; j < 4; j++)
+                        if (invalid & (0x80u << (8 * j))) { if (4 * i + j < FQZ_MAX_SEQUENCE_LENGTH) nn++; else beyond = 1; }
+                }
+            }
+        }
+        nn = wave_sum(nn);
+        beyond = wave_sum(beyond);
+        if (lane == 0) {
+            if (beyond) report_error(info, r, 4, FQZ_E_LONG_N);  // compress.go:477-488
+            if (nn > 65535u) { report_error(info, r, 5, FQZ_E_FIELD_WRAP); nn = 0; }
+            E[(size_t)S_NPOS * estride + r] = 2 + 2 * nn;
+        }
+    }
+}
+
+// ===========================================================================
+// K3/K4 quality delta, headers, plus payloads, lengths, N positions
+// (compress.go:495-519, quality.go:53-103)
+// ===========================================================================
+__device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
+{
+    for (uint32_t i = lane; i < n; i += WAVE) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void k_split_rest(const uint8_t *text, const uint32_t *ls, const EncInfo *info, const uint32_t *E,
+                                                    uint32_t estride, const BlockPlan *plans, uint32_t rpb, uint8_t *arena, uint8_t *npos_arena)
+{
+    uint32_t n_rec = info->n_rec, qoff = info->qual_off;
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    const uint32_t *Equal = E + (size_t)S_QUAL * estride, *Ehdr = E + (size_t)S_HDR * estride;
+    const uint32_t *Eplus = E + (size_t)S_PLUS * estride, *Enpos = E + (size_t)S_NPOS * estride;
+    for (uint32_t r = wave; r < n_rec; r += nwaves) {
+        uint32_t b = r / rpb;
+        const BlockPlan *p = &plans[b];
+        uint32_t r0 = p->rec0;
+        uint32_t L = Equal[r + 1] - Equal[r];
+        // ---- quality: q'[0] = q[0]-off, q'[i] = q[i]-q[i-1]  (delta restarts per record)
+        {
+            const uint8_t *q = text + ls[4 * r + 3];
+            uint8_t *dst = arena + p->a_off[S_QUAL] + (Equal[r] - Equal[r0]);
+            for (uint32_t base = 0; base < L; base += 4 * WAVE) {
+                uint32_t i = base + 4 * lane;
+                uint32_t x = 0, have = 0;
+                if (i < L) {
+                    have = L - i < 4 ? L - i : 4;
+                    if (have == 4) x = load_u32_unaligned(q + i);
+                    else for (uint32_t j = 0; j < have; j++) x |= (uint32_t)q[i + j] << (8 * j);
+                }
+                uint32_t prev = __shfl_up(x >> 24, 1, WAVE);
+                if (lane == 0) prev = base ? q[base - 1] : qoff;
+                uint32_t d = sub_bytes(x, (x << 8) | (prev & 0xFF));
+                if (have == 4) store_u32_unaligned(dst + i, d);
+                else for (uint32_t j = 0; j < have; j++) dst[i + j] = (uint8_t)(d >> (8 * j));
+            }
+        }
+        // ---- header: u16 H | bytes (without '@')
+        {
+            uint32_t H = Ehdr[r + 1] - Ehdr[r] - 2;
+            uint8_t *dst = arena + p->a_off[S_HDR] + (Ehdr[r] - Ehdr[r0]);
+            if (lane == 0) { dst[0] = (uint8_t)H; dst[1] = (uint8_t)(H >> 8); }
+            wave_copy_bytes(dst + 2, text + ls[4 * r] + 1, H, lane);
+        }
+        // ---- plus payload: u16 P | bytes (without '+')
+        {
+            uint32_t P = Eplus[r + 1] - Eplus[r] - 2;
+            uint8_t *dst = arena + p->a_off[S_PLUS] + (Eplus[r] - Eplus[r0]);
+            if (lane == 0) { dst[0] = (uint8_t)P; dst[1] = (uint8_t)(P >> 8); }
+            wave_copy_bytes(dst + 2, text + ls[4 * r + 2] + 1, P, lane);
+        }
+        // ---- length: u32 L
+        if (lane == 0) *(uint32_t *)(arena + p->a_off[S_LEN] + 4 * (r - r0)) = L;
+        // ---- N positions: u16 count | u16 positions (ascending, < 65536)
+        {
+            uint32_t nn = (Enpos[r + 1] - Enpos[r] - 2) >> 1;
+            uint8_t *dst = npos_arena + p->a_off[S_NPOS] + (Enpos[r] - Enpos[r0]);
+            if (lane == 0) { dst[0] = (uint8_t)nn; dst[1] = (uint8_t)(nn >> 8); }
+            if (nn) {
+                const uint8_t *sq = text + ls[4 * r + 1];
+                uint32_t limit = L < FQZ_MAX_SEQUENCE_LENGTH ? L : FQZ_MAX_SEQUENCE_LENGTH, run = 0;
+                for (uint32_t base = 0; base < limit; base += WAVE) {
+                    uint32_t i = base + lane;
+                    bool inv = false;
+                    if (i < limit) inv = (acgt_mask((uint32_t)sq[i] * 0x01010101u) & 0x80u) == 0;
+                    unsigned long long m = __ballot(inv);
+                    if (inv) {
+                        uint32_t k = run + __popcll(m & ((1ull << lane) - 1));
+                        dst[2 + 2 * k] = (uint8_t)i;
+                        dst[3 + 2 * k] = (uint8_t)(i >> 8);
+                    }
+                    run += __popcll(m);
+                }
+            }
+        }
+    }
+}
+
+// ===========================================================================
+// K5/K6 entropy stage: one workgroup per 16 KiB chunk -> one zstd block
+// (replaces zstd.Encoder.EncodeAll, compress.go:523-528; format: RFC 8878)
+// The construction is the deterministic "FQZ-H1" profile specified in DESIGN.md
+// and restated on the CPU in oracle/fqz_entropy.c; outputs are byte-identical.
+// ===========================================================================
+struct HufScratch {          // lives in the (not yet used) output staging buffer
+    uint32_t cnt[512];
+    uint16_t parent[512];
+    uint8_t depth[512];
+    uint8_t l[256];          // lengths in sorted order
+    uint8_t w[256];          // weights in symbol order
+    uint8_t tree[272];       // Huffman_Tree_Description
+    uint16_t state_table[64];
+    uint8_t table_symbol[64];
+};
+
+struct LdsBitW { uint8_t *p; unsigned long long acc; int nb; };
+__device__ __forceinline__ void bw_add(LdsBitW &b, uint32_t v, int n)
+{
+    b.acc |= (unsigned long long)v << b.nb;
+    b.nb += n;
+    while (b.nb >= 8) { *b.p++ = (uint8_t)b.acc; b.acc >>= 8; b.nb -= 8; }
+}
+
+// returns compressed size; 0 = not compressible; 1 = single symbol (mirrors oracle fse_compress_weights)
+__device__ uint32_t fse_compress_weights_dev(const uint8_t *w, int n, uint8_t *dst, HufScratch *sc)
+{
+    if (n <= 1) return 0;
+    int cnt[13], maxw = 0, maxc = 0;
+    for (int s = 0; s < 13; s++) cnt[s] = 0;
+    for (int i = 0; i < n; i++) { int x = w[i]; cnt[x]++; maxw = x > maxw ? x : maxw; }
+    for (int s = 0; s <= maxw; s++) maxc = cnt[s] > maxc ? cnt[s] : maxc;
+    if (maxc == n) return 1;
+    if (maxc == 1) return 0;
+    int table_log = 6;
+    {
+        int max_bits_src = highbit32_d((uint32_t)(n - 1)) - 2;
+        int min_bits_src = highbit32_d((uint32_t)n) + 1;
+        int min_bits_sym = highbit32_d((uint32_t)maxw) + 2;
+        int min_bits = min_bits_src < min_bits_sym ? min_bits_src : min_bits_sym;
+        if (max_bits_src < table_log) table_log = max_bits_src;
+        if (min_bits > table_log) table_log = min_bits;
+        if (table_log < 5) table_log = 5;
+        if (table_log > 6) table_log = 6;
+    }
+    int table_size = 1 << table_log;
+    int norm[13], present = 0, largest = 0;
+    for (int s = 0; s < 13; s++) norm[s] = 0;
+    for (int s = 0; s <= maxw; s++) {
+        if (cnt[s]) present++;
+        if (cnt[s] > cnt[largest]) largest = s;
+    }
+    int R = table_size - present, given = 0;
+    for (int s = 0; s <= maxw; s++)
+        if (cnt[s]) { int e = (cnt[s] * R) / n; norm[s] = 1 + e; given += e; }
+    norm[largest] += R - given;
+
+    uint8_t *op = dst;
+    {
+        uint32_t bits = 0;
+        int bc = 0;
+        int remaining = table_size + 1, threshold = table_size, nb = table_log + 1;
+        int sym = 0, alphabet = maxw + 1, prev0 = 0;
+        bits += (uint32_t)(table_log - 5) << bc; bc += 4;
+        while (sym < alphabet && remaining > 1) {
+            if (prev0) {
+                int start = sym;
+                while (sym < alphabet && !norm[sym]) sym++;
+                if (sym == alphabet) break;
+                while (sym >= start + 3) { start += 3; bits += 3u << bc; bc += 2; }
+                bits += (uint32_t)(sym - start) << bc; bc += 2;
+                if (bc > 16) { *op++ = (uint8_t)bits; *op++ = (uint8_t)(bits >> 8); bits >>= 16; bc -= 16; }
+            }
+            {
+                int c = norm[sym++];
+                int max = (2 * threshold - 1) - remaining;
+                remaining -= c;
+                c++;
+                if (c >= threshold) c += max;
+                bits += (uint32_t)c << bc;
+                bc += nb;
+                bc -= (c < max);
+                prev0 = (c == 1);
+                while (remaining < threshold) { nb--; threshold >>= 1; }
+            }
+            if (bc > 16) { *op++ = (uint8_t)bits; *op++ = (uint8_t)(bits >> 8); bits >>= 16; bc -= 16; }
+        }
+        if (bc > 0) *op++ = (uint8_t)bits;
+        if (bc > 8) *op++ = (uint8_t)(bits >> 8);
+    }
+    int delta_nb[13], delta_find[13];
+    {
+        int cumul[14];
+        cumul[0] = 0;
+        for (int s = 1; s <= maxw + 1; s++) cumul[s] = cumul[s - 1] + norm[s - 1];
+        int step = (table_size >> 1) + (table_size >> 3) + 3, mask = table_size - 1, pos = 0;
+        for (int s = 0; s <= maxw; s++)
+            for (int i = 0; i < norm[s]; i++) { sc->table_symbol[pos] = (uint8_t)s; pos = (pos + step) & mask; }
+        for (int u = 0; u < table_size; u++) { int s = sc->table_symbol[u]; sc->state_table[cumul[s]++] = (uint16_t)(table_size + u); }
+        int total = 0;
+        for (int s = 0; s <= maxw; s++) {
+            if (norm[s] == 0) { delta_nb[s] = ((table_log + 1) << 16) - table_size; delta_find[s] = 0; }
+            else if (norm[s] == 1) { delta_nb[s] = (table_log << 16) - table_size; delta_find[s] = total - 1; total++; }
+            else {
+                int max_bits_out = table_log - highbit32_d((uint32_t)(norm[s] - 1));
+                int min_state_plus = norm[s] << max_bits_out;
+                delta_nb[s] = (max_bits_out << 16) - min_state_plus;
+                delta_find[s] = total - norm[s];
+                total += norm[s];
+            }
+        }
+    }
+    LdsBitW bw = {op, 0ull, 0};
+    uint32_t st0 = 0, st1 = 0;
+    int in0 = 0, in1 = 0;
+    for (int i = n - 1; i >= 0; i--) {
+        int s = w[i];
+        uint32_t &st = (i & 1) ? st1 : st0;
+        int &inited = (i & 1) ? in1 : in0;
+        if (!inited) {
+            uint32_t nb_out = (uint32_t)(delta_nb[s] + (1 << 15)) >> 16;
+            uint32_t value = (nb_out << 16) - (uint32_t)delta_nb[s];
+            st = sc->state_table[(value >> nb_out) + delta_find[s]];
+            inited = 1;
+        } else {
+            uint32_t nb_out = (st + (uint32_t)delta_nb[s]) >> 16;
+            bw_add(bw, st & ((1u << nb_out) - 1), (int)nb_out);
+            st = sc->state_table[(st >> nb_out) + delta_find[s]];
+        }
+    }
+    bw_add(bw, st1 & (uint32_t)(table_size - 1), table_log);
+    bw_add(bw, st0 & (uint32_t)(table_size - 1), table_log);
+    bw_add(bw, 1, 1);
+    if (bw.nb) { *bw.p++ = (uint8_t)bw.acc; }
+    return (uint32_t)(bw.p - dst);
+}
+
+// Serial (one lane) table build: code lengths -> weights -> tree description.
+// keys: 256 sorted ascending (count<<8|sym), zeros first.  Returns tree size (0 = give up -> raw block),
+// writes nbits[256] and *max_bits.
+__device__ uint32_t huf_build_dev(const uint32_t *keys, int n_active, uint8_t *nbits, int *max_bits_out, HufScratch *sc)
+{
+    const uint32_t *key = keys + (256 - n_active);
+    int n = n_active;
+    for (int i = 0; i < n; i++) sc->cnt[i] = key[i] >> 8;
+    int li = 0, ih = n, it = n;
+    for (int k = 0; k < n - 1; k++) {
+        int a, b;
+        if (li < n && (ih >= it || sc->cnt[li] <= sc->cnt[ih])) a = li++; else a = ih++;
+        if (li < n && (ih >= it || sc->cnt[li] <= sc->cnt[ih])) b = li++; else b = ih++;
+        sc->cnt[it] = sc->cnt[a] + sc->cnt[b];
+        sc->parent[a] = sc->parent[b] = (uint16_t)it;
+        it++;
+    }
+    int root = 2 * n - 2;
+    sc->depth[root] = 0;
+    for (int v = root - 1; v >= 0; v--) sc->depth[v] = (uint8_t)(sc->depth[sc->parent[v]] + 1);
+    int maxd = 0;
+    for (int i = 0; i < n; i++) { sc->l[i] = sc->depth[i]; maxd = sc->l[i] > maxd ? sc->l[i] : maxd; }
+    if (maxd > FQZ_HUF_MAX_BITS) {
+        int K = 0;
+        for (int i = 0; i < n; i++) {
+            if (sc->l[i] > FQZ_HUF_MAX_BITS) sc->l[i] = FQZ_HUF_MAX_BITS;
+            K += 1 << (FQZ_HUF_MAX_BITS - sc->l[i]);
+        }
+        while (K > (1 << FQZ_HUF_MAX_BITS)) {
+            int best = -1;
+            for (int i = 0; i < n; i++)
+                if (sc->l[i] < FQZ_HUF_MAX_BITS && (best < 0 || sc->l[i] > sc->l[best])) best = i;
+            sc->l[best]++;
+            K -= 1 << (FQZ_HUF_MAX_BITS - sc->l[best]);
+        }
+        int slack = (1 << FQZ_HUF_MAX_BITS) - K;
+        while (slack > 0) {
+            for (int i = n - 1; i >= 0 && slack > 0; i--)
+                while (sc->l[i] > 1 && (1 << (FQZ_HUF_MAX_BITS - sc->l[i])) <= slack) {
+                    slack -= 1 << (FQZ_HUF_MAX_BITS - sc->l[i]);
+                    sc->l[i]--;
+                }
+        }
+        maxd = 0;
+        for (int i = 0; i < n; i++) maxd = sc->l[i] > maxd ? sc->l[i] : maxd;
+    }
+    for (int s = 0; s < 256; s++) nbits[s] = 0;
+    for (int i = 0; i < n; i++) nbits[key[i] & 0xFF] = sc->l[i];
+    *max_bits_out = maxd;
+
+    // Huffman_Tree_Description (oracle fqzo_huf_write_tree)
+    int max_sym = 255;
+    while (max_sym > 0 && !nbits[max_sym]) max_sym--;
+    int nw = max_sym;
+    for (int s = 0; s < nw; s++) sc->w[s] = nbits[s] ? (uint8_t)(maxd + 1 - nbits[s]) : 0;
+    uint32_t h = fse_compress_weights_dev(sc->w, nw, sc->tree + 1, sc);
+    if (h > 1 && h < (uint32_t)nw / 2) {
+        sc->tree[0] = (uint8_t)h;
+        return h + 1;
+    }
+    if (nw > 128) return 0;
+    sc->tree[0] = (uint8_t)(128 + (nw - 1));
+    sc->w[nw] = 0;
+    for (int i = 0; i < nw; i += 2) sc->tree[i / 2 + 1] = (uint8_t)((sc->w[i] << 4) + sc->w[i + 1]);
+    return (uint32_t)((nw + 1) / 2) + 1;
+}
+
+#define OUT_WORDS ((FQZ_CHUNK + 64) / 4)
+
+__global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const BlockPlan *plans, const uint8_t *arena, const uint8_t *npos_arena,
+                                                 uint8_t *slots, uint32_t *csize)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[FQZ_CHUNK / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[OUT_WORDS];
+    __shared__ uint32_t s_hist[4 * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_sorted[256];
+    __shared__ uint32_t s_ctab[256];
+    __shared__ uint8_t s_nbits[256];
+    __shared__ uint32_t s_misc[32];
+    // s_misc: 0 src offset, 1 m, 2 last, 3 stream id, 4 n_active, 5 mode (0 raw,1 rle,2 huf), 6 tree size, 7 max bits,
+    //         8..11 stream bit totals, 12 total bytes, 13 max count
+
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= info->n_chunks) return;
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+
+    if (t == 0) {
+        uint32_t nb = info->n_blocks, lo = 0, hi = nb;
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (plans[mid].chunk_base[0] <= chunk) lo = mid; else hi = mid; }
+        const BlockPlan *p = &plans[lo];
+        int s = 0;
+        for (int k = 0; k < FQZ_NS; k++) {
+            uint32_t nch = (p->len[k] + FQZ_CHUNK - 1) / FQZ_CHUNK;
+            if (nch && chunk >= p->chunk_base[k] && chunk < p->chunk_base[k] + nch) s = k;
+        }
+        uint32_t c = chunk - p->chunk_base[s];
+        uint32_t off = c * FQZ_CHUNK;
+        uint32_t m = p->len[s] - off < FQZ_CHUNK ? p->len[s] - off : FQZ_CHUNK;
+        s_misc[0] = p->a_off[s] + off;
+        s_misc[1] = m;
+        s_misc[2] = (off + m == p->len[s]);
+        s_misc[3] = (uint32_t)s;
+    }
+    for (uint32_t i = t; i < 4 * 256; i += 256) s_hist[i] = 0;
+    if (t < 4) s_chunk[FQZ_CHUNK / 4 + t] = 0;
+    __syncthreads();
+    const uint32_t m = s_misc[1], last = s_misc[2];
+    const uint8_t *src = (s_misc[3] == S_NPOS ? npos_arena : arena) + s_misc[0]; // 16-byte aligned
+    uint8_t *slot = slots + (size_t)chunk * FQZ_SLOT;
+
+    // ---- load chunk into LDS + per-wave histograms ---------------------------------
+    // Skewed data (quality deltas are mostly 0) would serialise LDS atomics on one bin: for each
+    // byte column the wave first peels off every lane that agrees with its first lane (one add).
+    {
+        uint32_t *hist = s_hist + wave * 256;
+        for (uint32_t q = t; q < FQZ_CHUNK / 16; q += 256) {
+            uint32_t off = q * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            uint32_t have = off < m ? (m - off < 16 ? m - off : 16) : 0;
+            if (have == 16) v = *(const uint4 *)(src + off);
+            else if (have) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; k < have; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *(uint4 *)&s_chunk[q * 4] = v;
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                bool act = k < have;
+                unsigned long long am = __ballot(act);
+                if (am) {
+                    int first = __ffsll((long long)am) - 1;
+                    uint32_t cand = __shfl(byte, first, WAVE);
+                    unsigned long long same = __ballot(act && byte == cand);
+                    if (lane == (uint32_t)first) atomicAdd(&hist[cand], (uint32_t)__popcll(same));
+                    if (act && byte != cand) atomicAdd(&hist[byte], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- merge histograms, classify -------------------------------------------------
+    {
+        uint32_t c = s_hist[t] + s_hist[256 + t] + s_hist[512 + t] + s_hist[768 + t];
+        s_keys[t] = c ? ((c << 8) | t) : 0u;
+        unsigned long long act = __ballot(c != 0);
+        uint32_t mx = c;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_xor(mx, d, WAVE); mx = o > mx ? o : mx; }
+        if (lane == 0) { s_misc[8 + wave] = (uint32_t)__popcll(act); s_misc[16 + wave] = mx; }
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t n_active = s_misc[8] + s_misc[9] + s_misc[10] + s_misc[11];
+        uint32_t mx = max(max(s_misc[16], s_misc[17]), max(s_misc[18], s_misc[19]));
+        s_misc[4] = n_active;
+        s_misc[13] = mx;
+        uint32_t mode = 2;
+        if (n_active == 1) mode = 1;                              // RLE block
+        else if (m < 64) mode = 0;                                // raw
+        else if ((unsigned long long)mx * 200ull <= m) mode = 0;  // near-flat histogram
+        s_misc[5] = mode;
+    }
+    __syncthreads();
+    uint32_t mode = s_misc[5];
+    const uint32_t n_active = s_misc[4];
+
+    if (mode == 2) {
+        // ---- rank sort of the 256 keys (ascending; distinct when non-zero, ties among zeros by index)
+        {
+            uint32_t my = s_keys[t], rank = 0;
+            for (uint32_t j = 0; j < 256; j += 4) {
+                uint4 k4 = *(const uint4 *)&s_keys[j];
+                rank += (k4.x < my) || (k4.x == my && j + 0 < t);
+                rank += (k4.y < my) || (k4.y == my && j + 1 < t);
+                rank += (k4.z < my) || (k4.z == my && j + 2 < t);
+                rank += (k4.w < my) || (k4.w == my && j + 3 < t);
+            }
+            s_sorted[rank] = my;
+        }
+        __syncthreads();
+        // ---- serial table build on one lane (scratch aliases the output staging buffer)
+        HufScratch *sc = (HufScratch *)s_out;
+        if (t == 0) {
+            int max_bits = 0;
+            uint32_t ts = huf_build_dev(s_sorted, (int)n_active, s_nbits, &max_bits, sc);
+            s_misc[6] = ts;
+            s_misc[7] = (uint32_t)max_bits;
+            if (!ts) s_misc[5] = 0;
+        }
+        __syncthreads();
+        mode = s_misc[5];
+    }
+    if (mode == 2) {
+        // ---- canonical codes (RFC 8878 4.2.1.3): from the longest length up, symbol order inside a length
+        const uint32_t max_bits = s_misc[7];
+        {
+            uint32_t nb = s_nbits[t];
+            // per-length counts via ballots; s_hist reused: [len] = count, [16+len] = first code
+            if (t < 32) s_hist[t] = 0;
+            __syncthreads();
+            uint32_t my_rank = 0;
+            for (uint32_t len = 1; len <= max_bits; len++) {
+                unsigned long long bm = __ballot(nb == len);
+                if (nb == len) my_rank = (uint32_t)__popcll(bm & ((1ull << lane) - 1));
+                if (lane == 0 && bm) s_hist[64 + wave * 16 + len] = (uint32_t)__popcll(bm);
+                else if (lane == 0) s_hist[64 + wave * 16 + len] = 0;
+            }
+            __syncthreads();
+            if (t == 0) {
+                uint32_t minv = 0;
+                for (uint32_t len = max_bits; len > 0; len--) {
+                    uint32_t cnt = s_hist[64 + len] + s_hist[80 + len] + s_hist[96 + len] + s_hist[112 + len];
+                    s_hist[16 + len] = minv;
+                    minv = (minv + cnt) >> 1;
+                }
+            }
+            __syncthreads();
+            uint32_t code = 0;
+            if (nb) {
+                uint32_t before = 0;
+                for (uint32_t w2 = 0; w2 < wave; w2++) before += s_hist[64 + w2 * 16 + nb];
+                code = s_hist[16 + nb] + before + my_rank;
+            }
+            s_ctab[t] = code | (nb << 16);
+        }
+        __syncthreads();
+        // copy the tree description out of the scratch before the staging buffer is cleared
+        uint32_t tree_size = s_misc[6];
+        uint8_t tree_byte = 0;
+        HufScratch *sc = (HufScratch *)s_out;
+        if (t < tree_size) tree_byte = sc->tree[t];
+        uint8_t tree_byte2 = 0;
+        if (t + 256 < tree_size) tree_byte2 = sc->tree[t + 256];
+        __syncthreads();
+        for (uint32_t i = t; i < OUT_WORDS; i += 256) s_out[i] = 0;
+        __syncthreads();
+
+        // ---- pass 1: bits per lane, per stream (wave w encodes stream w)
+        const uint32_t nstreams = m >= 256 ? 4 : 1;
+        const uint32_t seg = nstreams == 4 ? (m + 3) / 4 : m;
+        const uint32_t seg_base = wave * seg;
+        uint32_t seg_len = 0;
+        if (wave < nstreams) seg_len = (wave == nstreams - 1) ? m - seg_base : seg;
+        // symbols per lane: multiple of 4 with an odd dword count -> conflict-free LDS byte reads
+        uint32_t per = ((seg_len + 63) / 64 + 3) & ~3u;
+        if (((per >> 2) & 1) == 0) per += 4;
+        uint32_t a = lane * per, b = a + per;
+        if (a > seg_len) a = seg_len;
+        if (b > seg_len) b = seg_len;
+        const uint8_t *cb = (const uint8_t *)s_chunk + seg_base;
+        uint32_t my_bits = 0;
+        for (uint32_t j = a; j < b; j++) my_bits += s_ctab[cb[j]] >> 16;
+        uint32_t incl = wave_incl_scan(my_bits);
+        uint32_t tot_bits = __shfl(incl, 63, WAVE);
+        uint32_t bit_off = tot_bits - incl; // bits of all higher lanes = symbols written before mine
+        if (lane == 0) s_misc[8 + wave] = tot_bits;
+        __syncthreads();
+        // ---- sizes, raw fallback, headers (one lane; before any atomicOr touches those words)
+        if (t == 0) {
+            uint32_t ssz[4] = {0, 0, 0, 0}, total_streams = 0;
+            for (uint32_t k = 0; k < nstreams; k++) { ssz[k] = (s_misc[8 + k] >> 3) + 1; total_streams += ssz[k]; }
+            uint32_t lit_csize = tree_size + (nstreams == 4 ? 6 : 0) + total_streams;
+            uint32_t lh = m < 1024 ? 3 : (m < 16384 ? 4 : 5);
+            uint32_t content = lh + lit_csize + 1;
+            if (content >= m) s_misc[5] = 0;
+            else {
+                uint8_t *o = (uint8_t *)s_out;
+                uint32_t bh = (last & 1) | (2u << 1) | (content << 3);
+                o[0] = (uint8_t)bh; o[1] = (uint8_t)(bh >> 8); o[2] = (uint8_t)(bh >> 16);
+                if (lh == 3) {
+                    uint32_t v = 2u | ((nstreams == 4 ? 1u : 0u) << 2) | (m << 4) | (lit_csize << 14);
+                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16);
+                } else if (lh == 4) {
+                    uint32_t v = 2u | (2u << 2) | (m << 4) | (lit_csize << 18);
+                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
+                } else {
+                    uint32_t v = 2u | (3u << 2) | (m << 4) | (lit_csize << 22);
+                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
+                    o[7] = (uint8_t)(lit_csize >> 10);
+                }
+                uint32_t pos = 3 + lh + tree_size;
+                if (nstreams == 4) {
+                    for (int k = 0; k < 3; k++) { o[pos + 2 * k] = (uint8_t)ssz[k]; o[pos + 2 * k + 1] = (uint8_t)(ssz[k] >> 8); }
+                    pos += 6;
+                }
+                for (uint32_t k = 0; k < 4; k++) { s_misc[8 + k] = pos; pos += ssz[k]; } // stream start bytes
+                o[pos] = 0;                                                                // Number_of_Sequences = 0
+                s_misc[12] = pos + 1;
+                s_misc[14] = 3 + lh; // tree offset
+            }
+        }
+        __syncthreads();
+        mode = s_misc[5];
+        if (mode == 2) {
+            uint8_t *o = (uint8_t *)s_out;
+            uint32_t tree_off = s_misc[14];
+            if (t < tree_size) o[tree_off + t] = tree_byte;
+            if (t + 256 < tree_size) o[tree_off + t + 256] = tree_byte2;
+            __syncthreads();
+            // ---- pass 2: symbols last-to-first, LSB-first bit packing (HUF_compress1X order)
+            if (wave < nstreams) {
+                uint32_t P0 = 8 * s_misc[8 + wave] + bit_off;
+                uint32_t word = P0 >> 5;
+                uint32_t fill = P0 & 31;
+                unsigned long long acc = 0;
+                for (uint32_t j = b; j-- > a;) {
+                    uint32_t e = s_ctab[cb[j]];
+                    acc |= (unsigned long long)(e & 0xFFFF) << fill;
+                    fill += e >> 16;
+                    if (fill >= 32) { atomicOr(&s_out[word++], (uint32_t)acc); acc >>= 32; fill -= 32; }
+                }
+                if (lane == 0) { // end mark above the first symbol's code
+                    acc |= 1ull << fill;
+                    fill += 1;
+                    if (fill >= 32) { atomicOr(&s_out[word++], (uint32_t)acc); acc >>= 32; fill -= 32; }
+                }
+                if (fill) atomicOr(&s_out[word], (uint32_t)acc);
+            }
+            __syncthreads();
+            uint32_t total = s_misc[12];
+            uint32_t *slot32 = (uint32_t *)slot;
+            for (uint32_t i = t; i < (total + 3) / 4; i += 256) slot32[i] = s_out[i];
+            if (t == 0) csize[chunk] = total;
+            return;
+        }
+    }
+    if (mode == 1) { // RLE block: 3-byte header + the byte
+        if (t == 0) {
+            uint32_t bh = (last & 1) | (1u << 1) | (m << 3);
+            uint32_t b0 = ((const uint8_t *)s_chunk)[0];
+            *(uint32_t *)slot = (bh & 0xFFFFFF) | (b0 << 24);
+            csize[chunk] = 4;
+        }
+        return;
+    }
+    // raw block: 3-byte header + m bytes, composed dword-wise from the LDS copy
+    {
+        uint32_t bh = (last & 1) | (0u << 1) | (m << 3);
+        uint32_t total = 3 + m;
+        uint32_t *slot32 = (uint32_t *)slot;
+        for (uint32_t i = t; i < (total + 3) / 4; i += 256) {
+            uint32_t lo = i ? s_chunk[i - 1] : (bh << 8), hi = s_chunk[i];
+            // out bytes 4i..4i+3 = header/chunk bytes 4i-3..4i
+            slot32[i] = __builtin_amdgcn_alignbyte(hi, lo, 1);
+        }
+        if (t == 0) csize[chunk] = total;
+    }
+}
+
+// ===========================================================================
+// K7 framing (container.go:97-109, compress.go:532-552) + compaction
+// ===========================================================================
+__device__ __forceinline__ void put_le32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+// csize has been scanned in place (exclusive prefix, total at [n_chunks])
+__global__ void k_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t n_blocks = info->n_blocks;
+    unsigned long long pos = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        BlockPlan *p = &plans[b];
+        unsigned long long start = pos;
+        pos += 36;
+        for (int s = 0; s < FQZ_NS; s++) {
+            uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
+            uint32_t flen = nch ? 10 + (cpre[p->chunk_base[s] + nch] - cpre[p->chunk_base[s]]) : 0;
+            p->frame_off[s] = (uint32_t)pos;
+            p->frame_len[s] = flen;
+            pos += flen;
+            info->stream_comp[s] += flen;
+        }
+        p->out_off = (uint32_t)start;
+        p->out_len = (uint32_t)(pos - start);
+    }
+    info->out_len = pos;
+    if (pos > out_cap || pos > 0xFFFFFFF0ull) { if (!info->status) info->status = FQZ_E_DST_SMALL; return; }
+    if (info->status) return;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        BlockPlan *p = &plans[b];
+        uint8_t *h = out + p->out_off;
+        // BlockHeader v2: NumRecords, Seq, Qual, Header, Plus, NPositions, SeqLengths, OriginalSeq, OriginalQual
+        put_le32(h + 0, p->nrec);
+        put_le32(h + 4, p->frame_len[S_SEQ]);
+        put_le32(h + 8, p->frame_len[S_QUAL]);
+        put_le32(h + 12, p->frame_len[S_HDR]);
+        put_le32(h + 16, p->frame_len[S_PLUS]);
+        put_le32(h + 20, p->frame_len[S_NPOS]);
+        put_le32(h + 24, p->frame_len[S_LEN]);
+        put_le32(h + 28, p->orig_seq);
+        put_le32(h + 32, p->orig_seq);
+        for (int s = 0; s < FQZ_NS; s++) {
+            if (!p->frame_len[s]) continue;
+            uint8_t *f = out + p->frame_off[s];
+            f[0] = 0x28; f[1] = 0xB5; f[2] = 0x2F; f[3] = 0xFD; // zstd magic
+            f[4] = 0x80;                                        // FCS 4 bytes, windowed, no checksum
+            f[5] = 0x38;                                        // window 128 KiB
+            put_le32(f + 6, p->len[s]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const BlockPlan *plans, const uint8_t *slots, const uint32_t *cpre,
+                                                 uint8_t *out)
+{
+    __shared__ uint32_t sh[2];
+    const uint32_t chunk = blockIdx.x;
+    if (info->status || chunk >= info->n_chunks) return;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) {
+        uint32_t nb = info->n_blocks, lo = 0, hi = nb;
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (plans[mid].chunk_base[0] <= chunk) lo = mid; else hi = mid; }
+        const BlockPlan *p = &plans[lo];
+        int s = 0;
+        for (int k = 0; k < FQZ_NS; k++) {
+            uint32_t nch = (p->len[k] + FQZ_CHUNK - 1) / FQZ_CHUNK;
+            if (nch && chunk >= p->chunk_base[k] && chunk < p->chunk_base[k] + nch) s = k;
+        }
+        sh[0] = p->frame_off[s] + 10 + (cpre[chunk] - cpre[p->chunk_base[s]]);
+        sh[1] = cpre[chunk + 1] - cpre[chunk];
+    }
+    __syncthreads();
+    uint8_t *dst = out + sh[0];
+    const uint32_t n = sh[1];
+    const uint8_t *src = slots + (size_t)chunk * FQZ_SLOT; // 16-byte aligned
+    uint32_t head = (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3);
+    if (head > n) head = n;
+    if (t < head) dst[t] = src[t];
+    uint32_t body = (n - head) >> 2;
+    const uint32_t *s32 = (const uint32_t *)src;
+    uint32_t *d32 = (uint32_t *)(dst + head);
+    for (uint32_t j = t; j < body; j += 256) {
+        uint32_t sb = head + 4 * j;          // source byte offset of this dword
+        uint32_t lo = s32[sb >> 2], hi = s32[(sb >> 2) + 1]; // slot padding keeps hi in bounds
+        d32[j] = __builtin_amdgcn_alignbyte(hi, lo, sb & 3);
+    }
+    uint32_t tail0 = head + 4 * body;
+    if (t < n - tail0) dst[tail0 + t] = src[tail0 + t];
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+static inline uint32_t grid_for_waves(uint32_t n_items)
+{
+    // one wave per item, 4 waves per workgroup, capped: the kernels grid-stride
+    uint32_t g = (n_items + 3) / 4;
+    if (g > 8192) g = 8192;
+    return g ? g : 1;
+}
+
+int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags, uint8_t *d_out,
+                   size_t out_cap, hipStream_t st)
+{
+    EncState &e = ctx->enc;
+    if (e.in_flight) return FQZ_E_ARG;
+    if (!rpb) rpb = FQZ_DEFAULT_BLOCK_SIZE;
+    if (n_bytes >= 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
+    if (((uintptr_t)d_text & 15) || ((uintptr_t)d_out & 15)) return FQZ_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t n = (uint32_t)n_bytes;
+    const uint32_t final_batch = (flags & FQZ_BATCH_FINAL) ? 1u : 0u;
+
+    // ---- capacities (grown lazily; the line capacity assumes >= 8 bytes per line and is retried on overflow)
+    e.n_tiles = (n + FQZ_TILE - 1) / FQZ_TILE;
+    uint32_t line_cap = n / 8 + 1024;
+    if (e.line_cap > line_cap && e.n_bytes == n_bytes) line_cap = e.line_cap; // keep a grown capacity on retry
+    e.line_cap = line_cap;
+    e.rec_cap = line_cap / 4 + 1;
+    e.block_cap = e.rec_cap / rpb + 2;
+    e.arena_cap = (size_t)n + 4ull * e.rec_cap + 96ull * e.block_cap + 4096;
+    e.npos_cap = (size_t)n + 2ull * e.rec_cap + 16ull * e.block_cap + 4096;
+    size_t chunk_cap = (e.arena_cap + e.npos_cap) / FQZ_CHUNK + 6ull * e.block_cap + 8;
+    if (chunk_cap > 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
+    e.chunk_cap = (uint32_t)chunk_cap;
+    const uint32_t estride = e.rec_cap + 1;
+
+    int rc;
+    if ((rc = e.info.ensure(sizeof(EncInfo)))) return rc;
+    if ((rc = e.tile_cnt.ensure(4ull * (e.n_tiles + 2)))) return rc;
+    if ((rc = e.ls.ensure(4ull * (e.line_cap + 2)))) return rc;
+    if ((rc = e.E.ensure(4ull * 5 * estride))) return rc;
+    if ((rc = e.plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
+    if ((rc = e.arena.ensure(e.arena_cap + 64))) return rc;
+    if ((rc = e.npos.ensure(e.npos_cap + 64))) return rc;
+    if ((rc = e.slots.ensure((size_t)e.chunk_cap * FQZ_SLOT))) return rc;
+    if ((rc = e.csize.ensure(4ull * (e.chunk_cap + 2)))) return rc;
+    uint32_t pmax = e.rec_cap / SCAN_TILE + 2;
+    if (e.n_tiles / SCAN_TILE + 2 > pmax) pmax = e.n_tiles / SCAN_TILE + 2;
+    if (e.chunk_cap / SCAN_TILE + 2 > pmax) pmax = e.chunk_cap / SCAN_TILE + 2;
+    if ((rc = e.partials.ensure(4ull * 5 * pmax))) return rc;
+    if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
+    if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
+
+    e.d_text = d_text; e.n_bytes = n_bytes; e.rpb = rpb; e.flags = flags; e.d_out = d_out; e.out_cap = out_cap; e.stream = st;
+
+    EncInfo *info = e.info.as<EncInfo>();
+    uint32_t *tile = e.tile_cnt.as<uint32_t>(), *ls = e.ls.as<uint32_t>(), *E = e.E.as<uint32_t>();
+    uint32_t *partials = e.partials.as<uint32_t>(), *csize = e.csize.as<uint32_t>();
+    BlockPlan *plans = e.plans.as<BlockPlan>();
+    uint8_t *arena = e.arena.as<uint8_t>(), *npos = e.npos.as<uint8_t>(), *slots = e.slots.as<uint8_t>();
+
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, qual_encoding);
+    if (e.n_tiles) {
+        hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile);
+        launch_scan(st, tile, nullptr, e.n_tiles, e.n_tiles, 1, e.n_tiles + 1, partials, pmax);
+        hipLaunchKernelGGL(k_line_starts, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile, ls, e.line_cap);
+    } else {
+        HIP_TRY(hipMemsetAsync(tile, 0, 8, st));
+        HIP_TRY(hipMemsetAsync(ls, 0, 8, st));
+    }
+    hipLaunchKernelGGL(k_setup_records, dim3(1), dim3(64), 0, st, info, tile, e.n_tiles, ls, e.line_cap, e.rec_cap, e.block_cap, rpb,
+                       final_batch, n);
+    uint32_t rec_grid = (e.rec_cap + 255) / 256;
+    if (rec_grid > 4096) rec_grid = 4096;
+    hipLaunchKernelGGL(k_record_meta, dim3(rec_grid), dim3(256), 0, st, d_text, ls, info, E, estride, final_batch);
+    if (qual_encoding == FQZ_DETECT_ENCODING) {
+        hipLaunchKernelGGL(k_detect, dim3(grid_for_waves(rpb < e.rec_cap ? rpb : e.rec_cap)), dim3(256), 0, st, d_text, ls, info, rpb);
+        hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
+    }
+    launch_scan(st, E, &info->n_rec, 0, e.rec_cap, 4, estride, partials, pmax); // seq, qual, hdr, plus
+    hipLaunchKernelGGL(k_plan1, dim3(1), dim3(64), 0, st, info, E, estride, plans, rpb, e.arena_cap);
+    hipLaunchKernelGGL(k_split_seq, dim3(grid_for_waves(e.rec_cap)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena);
+    launch_scan(st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
+    hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap);
+    hipLaunchKernelGGL(k_split_rest, dim3(grid_for_waves(e.rec_cap)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena, npos);
+    hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize);
+    launch_scan(st, csize, &info->n_chunks, 0, e.chunk_cap, 1, e.chunk_cap + 1, partials, pmax);
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_out, out_cap);
+    hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
+    e.in_flight = true;
+    return FQZ_OK;
+}
+
+int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uint64_t *block_len, size_t max_blocks)
+{
+    EncState &e = ctx->enc;
+    if (!e.in_flight) return FQZ_E_ARG;
+    e.in_flight = false;
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    const EncInfo *hi = e.h_info.as<EncInfo>();
+    if (res) {
+        memset(res, 0, sizeof *res);
+        res->n_records = hi->n_rec;
+        res->n_blocks = hi->n_blocks;
+        res->consumed = hi->consumed;
+        res->out_len = hi->status ? 0 : hi->out_len;
+        res->status = hi->status;
+        res->error_record = hi->error_record;
+        res->qual_encoding = hi->qual_off == 64 ? FQZ_ENCODING_PHRED64 : FQZ_ENCODING_PHRED33;
+        res->n_chunks = hi->n_chunks;
+        for (int s = 0; s < FQZ_NS; s++) { res->stream_raw[s] = hi->stream_raw[s]; res->stream_comp[s] = hi->stream_comp[s]; }
+    }
+    if (hi->status == FQZ_E_TOO_LARGE && hi->n_lines > e.line_cap) {
+        // more lines than the optimistic capacity: remember the exact need so that a relaunch fits
+        e.line_cap = hi->n_lines + 16;
+        return FQZ_E_TOO_LARGE;
+    }
+    if (hi->status) return hi->status;
+    if ((block_off || block_len) && hi->n_blocks) {
+        if (hi->n_blocks > max_blocks) return FQZ_E_DST_SMALL;
+        HIP_TRY(hipMemcpyAsync(e.h_plans.p, e.plans.p, sizeof(BlockPlan) * (size_t)hi->n_blocks, hipMemcpyDeviceToHost, e.stream));
+        HIP_TRY(hipStreamSynchronize(e.stream));
+        const BlockPlan *hp = e.h_plans.as<BlockPlan>();
+        for (uint32_t b = 0; b < hi->n_blocks; b++) {
+            if (block_off) block_off[b] = hp[b].out_off;
+            if (block_len) block_len[b] = hp[b].out_len;
+        }
+    }
+    return FQZ_OK;
+}
+
+int fqz_enc_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_t stream_len[6])
+{
+    EncState &e = ctx->enc;
+    const EncInfo *hi = e.h_info.as<EncInfo>();
+    if (!hi || e.in_flight || block >= hi->n_blocks) return FQZ_E_ARG;
+    BlockPlan p;
+    HIP_TRY(hipMemcpy(&p, e.plans.as<BlockPlan>() + block, sizeof p, hipMemcpyDeviceToHost));
+    for (int s = 0; s < FQZ_NS; s++) {
+        size_t cap = stream_len[s];
+        stream_len[s] = p.len[s];
+        if (!streams || !streams[s]) continue;
+        if (cap < p.len[s]) return FQZ_E_DST_SMALL;
+        const uint8_t *base = (s == S_NPOS ? e.npos.as<uint8_t>() : e.arena.as<uint8_t>()) + p.a_off[s];
+        if (p.len[s]) HIP_TRY(hipMemcpy(streams[s], base, p.len[s], hipMemcpyDeviceToHost));
+    }
+    return FQZ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// entropy stage alone: one stream -> one zstd frame (unit-level parity with the oracle)
+// ---------------------------------------------------------------------------
+__global__ void k_single_plan(EncInfo *info, BlockPlan *plans, uint32_t n)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    BlockPlan p;
+    memset(&p, 0, sizeof p);
+    p.nrec = 1;
+    p.len[S_SEQ] = n;
+    uint32_t chunks = (n + FQZ_CHUNK - 1) / FQZ_CHUNK;
+    for (int s = 1; s < FQZ_NS; s++) p.chunk_base[s] = chunks;
+    plans[0] = p;
+    info->n_blocks = 1;
+    info->n_chunks = chunks;
+}
+
+__global__ void k_single_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    BlockPlan *p = &plans[0];
+    uint32_t flen = 10 + cpre[info->n_chunks];
+    p->frame_off[S_SEQ] = 0;
+    p->frame_len[S_SEQ] = flen;
+    info->out_len = flen;
+    if (flen > out_cap) { info->status = FQZ_E_DST_SMALL; return; }
+    out[0] = 0x28; out[1] = 0xB5; out[2] = 0x2F; out[3] = 0xFD; out[4] = 0x80; out[5] = 0x38;
+    put_le32(out + 6, p->len[S_SEQ]);
+}
+
+int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, size_t *out_len, hipStream_t st)
+{
+    EncState &e = ctx->enc;
+    if (e.in_flight || n >= 0x7FFFFFFFull || ((uintptr_t)d_src & 15)) return FQZ_E_ARG;
+    uint32_t chunks = (uint32_t)((n + FQZ_CHUNK - 1) / FQZ_CHUNK);
+    int rc;
+    if ((rc = e.info.ensure(sizeof(EncInfo)))) return rc;
+    if ((rc = e.plans.ensure(sizeof(BlockPlan) * 2))) return rc;
+    if ((rc = e.slots.ensure((size_t)(chunks + 1) * FQZ_SLOT))) return rc;
+    if ((rc = e.csize.ensure(4ull * (chunks + 2)))) return rc;
+    if ((rc = e.partials.ensure(4ull * (chunks / SCAN_TILE + 2)))) return rc;
+    if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
+    EncInfo *info = e.info.as<EncInfo>();
+    BlockPlan *plans = e.plans.as<BlockPlan>();
+    uint32_t *csize = e.csize.as<uint32_t>();
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, 0);
+    hipLaunchKernelGGL(k_single_plan, dim3(1), dim3(64), 0, st, info, plans, (uint32_t)n);
+    hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize);
+    launch_scan(st, csize, &info->n_chunks, 0, chunks, 1, chunks + 1, e.partials.as<uint32_t>(), chunks / SCAN_TILE + 2);
+    hipLaunchKernelGGL(k_single_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_dst, cap);
+    hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, d_dst);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const EncInfo *hi = e.h_info.as<EncInfo>();
+    if (hi->status) return hi->status;
+    *out_len = hi->out_len;
+    return FQZ_OK;
+}

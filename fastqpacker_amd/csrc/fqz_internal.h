@@ -1,0 +1,68 @@
+// fqz_internal.h — shared declarations of libfqzhip (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "fqz.h"
+
+#define FQZ_CHUNK 16384u               // pre-entropy bytes per zstd block (== FQZ_ENTROPY_CHUNK)
+#define FQZ_SLOT (FQZ_CHUNK + 64u)     // per-chunk staging slot in HBM (raw worst case 3+16384, padded for aligned reads)
+#define FQZ_TILE 4096u                 // text bytes per line-index workgroup
+#define FQZ_NS 6
+enum { S_SEQ = 0, S_QUAL = 1, S_HDR = 2, S_PLUS = 3, S_NPOS = 4, S_LEN = 5 };
+
+#define FQZ_HUF_MAX_BITS 11
+
+// Device-resident scalar state of one encode batch.
+struct EncInfo {
+    uint32_t n_lines;       // '\n' count of the batch text
+    uint32_t n_rec;         // records encoded
+    uint32_t n_rec_total;   // whole records present
+    uint32_t n_blocks;
+    uint32_t consumed;      // text bytes consumed
+    int32_t  status;        // fqz_status
+    uint32_t error_record;
+    uint32_t min_qual;      // min quality byte of block 0 (DetectEncoding)
+    uint32_t qual_off;      // 33 or 64
+    uint32_t n_chunks;
+    uint32_t arena_used;    // bytes of the main arena in use
+    uint32_t npos_used;
+    unsigned long long error_key; // (record << 8 | check order << 4 | code index), min wins
+    unsigned long long out_len;
+    unsigned long long stream_raw[FQZ_NS];
+    unsigned long long stream_comp[FQZ_NS];
+};
+
+// Per-block plan: where each pre-entropy stream of block b lives and its chunks.
+struct BlockPlan {
+    uint32_t rec0, nrec;
+    uint32_t a_off[FQZ_NS];      // byte offset in the arena (S_NPOS: in the npos arena), 16-aligned
+    uint32_t len[FQZ_NS];        // pre-entropy bytes
+    uint32_t chunk_base[FQZ_NS]; // first chunk id
+    uint32_t frame_off[FQZ_NS];  // offset of the payload in d_out (filled by layout)
+    uint32_t frame_len[FQZ_NS];
+    uint32_t out_off, out_len;   // block header + payloads in d_out
+    uint32_t orig_seq;           // sum of read lengths
+};
+
+// Decode side -------------------------------------------------------------
+struct DecInfo {
+    int32_t  status;
+    uint32_t n_blocks;
+    uint32_t n_rec;
+    uint32_t n_chunks;
+    unsigned long long out_len;
+    unsigned long long stream_raw[FQZ_NS];
+    unsigned long long stream_comp[FQZ_NS];
+};
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return fqz_set_hip_error(_e, #expr); \
+    } while (0)
+
+int fqz_set_hip_error(hipError_t e, const char *what);
+
+static inline size_t fqz_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

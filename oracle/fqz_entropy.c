@@ -16,7 +16,8 @@
  *            | Frame_Content_Size u32le | blocks...            (no checksum)
  *   block  = one per FQZO_CHUNK (16 KiB) bytes of the stream, in order:
  *            RLE block        when all bytes are equal,
- *            Raw block        when m < 64 or Huffman does not shrink it,
+ *            Raw block        when m < 64, when the histogram is near-flat
+ *                             (max count * 200 <= m) or Huffman does not shrink it,
  *            Compressed block = Huffman-coded literals (1 stream if m < 256,
  *            else 4 streams) + "0 sequences".
  *   empty stream -> 0 bytes (klauspost EncodeAll without WithZeroFrames).
@@ -319,6 +320,11 @@ size_t fqzo_encode_chunk(const uint8_t *src, size_t m, int last, uint8_t *dst)
         return 4;
     }
     if (m < 64) return raw_block(src, m, last, dst);
+    {   /* near-flat histogram (p_max <= 1/200, i.e. >= 7.6 bits/symbol): not worth a table */
+        uint32_t maxc = 0;
+        for (int s = 0; s < 256; s++) if (count[s] > maxc) maxc = count[s];
+        if ((uint64_t)maxc * 200 <= m) return raw_block(src, m, last, dst);
+    }
 
     uint8_t nbits[256];
     uint16_t code[256];
