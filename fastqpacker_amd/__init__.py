@@ -8,3 +8,5 @@ from ._lib import (FqzError, Ctx, lib, build, library_path,  # noqa: F401
                    ENCODING_PHRED33, ENCODING_PHRED64, DETECT_ENCODING, BATCH_FINAL, DEFAULT_BLOCK_SIZE,
                    STREAM_NAMES, Options, DecompressOptions)
 from . import encoder, compress, fqformat  # noqa: F401
+# fastqpacker_amd.sharding needs torch.distributed and is imported on demand
+

@@ -107,6 +107,9 @@ SIGNATURES = {
     "fqz_decompress": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(DecompressOptions)]),
     "fqz_compress_file": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.POINTER(Options)]),
     "fqz_decompress_file": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.POINTER(DecompressOptions)]),
+    "fqz_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "fqz_profile_reset": (C.c_int, [_vp]),
+    "fqz_profile_read": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t)]),
     "fqz_synth_fastq": (C.c_int, [C.POINTER(SynthParams), C.c_uint64, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
 }
 
@@ -161,6 +164,25 @@ class Ctx:
         except Exception:
             pass
 
+
+def _ctx_profile(self, on=True):
+    check(lib().fqz_profile_enable(self._h, 1 if on else 0))
+    check(lib().fqz_profile_reset(self._h))
+
+
+def _ctx_profile_read(self):
+    """{kernel: (total_ms, calls)} accumulated since the last profile(True)/reset."""
+    names = C.create_string_buffer(4096)
+    ms = (C.c_double * 64)()
+    calls = (C.c_uint32 * 64)()
+    n = C.c_size_t(0)
+    check(lib().fqz_profile_read(self._h, names, 4096, ms, calls, 64, C.byref(n)))
+    keys = names.value.decode().split("\n") if n.value else []
+    return {k: (ms[i], calls[i]) for i, k in enumerate(keys)}
+
+
+Ctx.profile = _ctx_profile
+Ctx.profile_read = _ctx_profile_read
 
 _default = {}
 

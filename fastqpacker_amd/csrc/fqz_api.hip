@@ -102,6 +102,8 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     DevBuf *db[] = {&d.info, &d.blocks, &d.chunks, &d.streams, &d.rec, &d.partials, &d.tables};
     for (DevBuf *b : db) b->release();
     d.h_info.release(); d.h_blocks.release();
+    c->prof.collect();
+    for (hipEvent_t ev : c->prof.pool) (void)hipEventDestroy(ev);
     c->d_in.release(); c->d_out.release(); c->h_stage.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -683,6 +685,41 @@ extern "C" int fqz_entropy_decode(fqz_ctx *ctx, const uint8_t *src, size_t n, ui
     if (rc) return rc;
     if (got) HIP_TRY(hipMemcpy(dst, ctx->d_out.p, got, hipMemcpyDeviceToHost));
     *out_len = got;
+    return FQZ_OK;
+}
+
+// ===========================================================================
+// per-kernel timing
+// ===========================================================================
+extern "C" int fqz_profile_enable(fqz_ctx *ctx, int on)
+{
+    if (!ctx) return FQZ_E_ARG;
+    ctx->prof.on = on != 0;
+    return FQZ_OK;
+}
+extern "C" int fqz_profile_reset(fqz_ctx *ctx)
+{
+    if (!ctx) return FQZ_E_ARG;
+    ctx->prof.collect();
+    ctx->prof.totals.clear();
+    return FQZ_OK;
+}
+extern "C" int fqz_profile_read(fqz_ctx *ctx, char *names, size_t names_cap, double *ms, uint32_t *calls, size_t max_entries, size_t *n_entries)
+{
+    if (!ctx || !n_entries) return FQZ_E_ARG;
+    ctx->prof.collect();
+    std::string all;
+    size_t n = 0;
+    for (const ProfTotal &t : ctx->prof.totals) {
+        if (n >= max_entries) break;
+        if (n) all += "\n";
+        all += t.name;
+        if (ms) ms[n] = t.ms;
+        if (calls) calls[n] = t.calls;
+        n++;
+    }
+    if (names && names_cap) { size_t k = all.size() < names_cap - 1 ? all.size() : names_cap - 1; memcpy(names, all.data(), k); names[k] = 0; }
+    *n_entries = n;
     return FQZ_OK;
 }
 

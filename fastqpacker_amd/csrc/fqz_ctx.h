@@ -2,6 +2,9 @@
 #pragma once
 #include "fqz_internal.h"
 
+#include <string>
+#include <vector>
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -90,7 +93,52 @@ struct DecState {
     uint32_t n_blocks = 0;
 };
 
+struct ProfEntry { const char *name; hipEvent_t a, b; };
+struct ProfTotal { std::string name; double ms; uint32_t calls; };
+struct Prof {
+    bool on = false;
+    std::vector<ProfEntry> pending;
+    std::vector<hipEvent_t> pool;
+    std::vector<ProfTotal> totals;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void begin(const char *name, hipStream_t st)
+    {
+        if (!on) return;
+        ProfEntry e{name, get(), get()};
+        (void)hipEventRecord(e.a, st);
+        pending.push_back(e);
+    }
+    void end(hipStream_t st)
+    {
+        if (!on || pending.empty()) return;
+        (void)hipEventRecord(pending.back().b, st);
+    }
+    void collect() // call after the stream has been synchronised
+    {
+        for (ProfEntry &e : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+                bool found = false;
+                for (ProfTotal &t : totals) if (t.name == e.name) { t.ms += ms; t.calls++; found = true; break; }
+                if (!found) totals.push_back(ProfTotal{e.name, ms, 1});
+            }
+            pool.push_back(e.a);
+            pool.push_back(e.b);
+        }
+        pending.clear();
+    }
+};
+// brackets one launch: PROF(ctx, st, "name", hipLaunchKernelGGL(...));
+#define PROF(ctx, st, name, launch) do { (ctx)->prof.begin(name, st); launch; (ctx)->prof.end(st); } while (0)
+
 struct fqz_ctx {
+    Prof prof;
     int device = 0;
     hipStream_t stream = nullptr;
     EncState enc;

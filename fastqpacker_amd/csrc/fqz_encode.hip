@@ -77,14 +77,16 @@ __global__ __launch_bounds__(256) void k_scan_apply(uint32_t *data, const uint32
 }
 
 // data: ncols columns of (cap+1) u32, scanned in place; data[col][n] receives the total
-static void launch_scan(hipStream_t st, uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t n_cap, uint32_t ncols,
+static void launch_scan(fqz_ctx *ctx, const char *label, hipStream_t st, uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t n_cap, uint32_t ncols,
                         uint32_t col_stride, uint32_t *partials, uint32_t pstride)
 {
     uint32_t nwg = (n_cap + SCAN_TILE - 1) / SCAN_TILE;
     if (nwg == 0) nwg = 1;
+    ctx->prof.begin(label, st);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nwg, ncols), dim3(256), 0, st, data, n_ptr, n_add, col_stride, partials, pstride);
     hipLaunchKernelGGL(k_scan_top, dim3(ncols), dim3(256), 0, st, data, n_ptr, n_add, col_stride, partials, pstride);
     hipLaunchKernelGGL(k_scan_apply, dim3(nwg, ncols), dim3(256), 0, st, data, n_ptr, n_add, col_stride, partials, pstride);
+    ctx->prof.end(st);
 }
 
 // ===========================================================================
@@ -1075,32 +1077,32 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
 
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, qual_encoding);
     if (e.n_tiles) {
-        hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile);
-        launch_scan(st, tile, nullptr, e.n_tiles, e.n_tiles, 1, e.n_tiles + 1, partials, pmax);
-        hipLaunchKernelGGL(k_line_starts, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile, ls, e.line_cap);
+        PROF(ctx, st, "k_count_nl", hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile));
+        launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, 1, e.n_tiles + 1, partials, pmax);
+        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile, ls, e.line_cap));
     } else {
         HIP_TRY(hipMemsetAsync(tile, 0, 8, st));
         HIP_TRY(hipMemsetAsync(ls, 0, 8, st));
     }
-    hipLaunchKernelGGL(k_setup_records, dim3(1), dim3(64), 0, st, info, tile, e.n_tiles, ls, e.line_cap, e.rec_cap, e.block_cap, rpb,
-                       final_batch, n);
+    PROF(ctx, st, "k_setup_records", hipLaunchKernelGGL(k_setup_records, dim3(1), dim3(64), 0, st, info, tile, e.n_tiles, ls, e.line_cap, e.rec_cap, e.block_cap, rpb,
+                       final_batch, n));
     uint32_t rec_grid = (e.rec_cap + 255) / 256;
     if (rec_grid > 4096) rec_grid = 4096;
-    hipLaunchKernelGGL(k_record_meta, dim3(rec_grid), dim3(256), 0, st, d_text, ls, info, E, estride, final_batch);
+    PROF(ctx, st, "k_record_meta", hipLaunchKernelGGL(k_record_meta, dim3(rec_grid), dim3(256), 0, st, d_text, ls, info, E, estride, final_batch));
     if (qual_encoding == FQZ_DETECT_ENCODING) {
-        hipLaunchKernelGGL(k_detect, dim3(grid_for_waves(rpb < e.rec_cap ? rpb : e.rec_cap)), dim3(256), 0, st, d_text, ls, info, rpb);
+        PROF(ctx, st, "k_detect", hipLaunchKernelGGL(k_detect, dim3(grid_for_waves(rpb < e.rec_cap ? rpb : e.rec_cap)), dim3(256), 0, st, d_text, ls, info, rpb));
         hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
     }
-    launch_scan(st, E, &info->n_rec, 0, e.rec_cap, 4, estride, partials, pmax); // seq, qual, hdr, plus
-    hipLaunchKernelGGL(k_plan1, dim3(1), dim3(64), 0, st, info, E, estride, plans, rpb, e.arena_cap);
-    hipLaunchKernelGGL(k_split_seq, dim3(grid_for_waves(e.rec_cap)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena);
-    launch_scan(st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
-    hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap);
-    hipLaunchKernelGGL(k_split_rest, dim3(grid_for_waves(e.rec_cap)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena, npos);
-    hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize);
-    launch_scan(st, csize, &info->n_chunks, 0, e.chunk_cap, 1, e.chunk_cap + 1, partials, pmax);
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_out, out_cap);
-    hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out);
+    launch_scan(ctx, "scan_records", st, E, &info->n_rec, 0, e.rec_cap, 4, estride, partials, pmax); // seq, qual, hdr, plus
+    PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(64), 0, st, info, E, estride, plans, rpb, e.arena_cap));
+    PROF(ctx, st, "k_split_seq", hipLaunchKernelGGL(k_split_seq, dim3(grid_for_waves(e.rec_cap)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena));
+    launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
+    PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
+    PROF(ctx, st, "k_split_rest", hipLaunchKernelGGL(k_split_rest, dim3(grid_for_waves(e.rec_cap)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena, npos));
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize));
+    launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, 1, e.chunk_cap + 1, partials, pmax);
+    PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_out, out_cap));
+    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
     e.in_flight = true;
@@ -1210,10 +1212,10 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     uint32_t *csize = e.csize.as<uint32_t>();
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, 0);
     hipLaunchKernelGGL(k_single_plan, dim3(1), dim3(64), 0, st, info, plans, (uint32_t)n);
-    hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize);
-    launch_scan(st, csize, &info->n_chunks, 0, chunks, 1, chunks + 1, e.partials.as<uint32_t>(), chunks / SCAN_TILE + 2);
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize));
+    launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks, 1, chunks + 1, e.partials.as<uint32_t>(), chunks / SCAN_TILE + 2);
     hipLaunchKernelGGL(k_single_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_dst, cap);
-    hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, d_dst);
+    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, d_dst));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles its own HIP runtime: it must be loaded before libfqzhip.so so both share one copy
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 

@@ -1,0 +1,142 @@
+"""GPU parity, decode side and whole-file round trips through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fastq_gen import make_fastq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fq():
+    import fastqpacker_amd as fq
+    fq.lib()
+    return fq
+
+
+CASES = {
+    "sample": None,
+    "fixed150": dict(n_records=2000, seed=1),
+    "ragged_N_phred64": dict(n_records=1500, seed=2, min_len=35, max_len=301, n_frac=0.05, phred=64, plus_payload=True),
+    "short": dict(n_records=300, seed=3, min_len=0, max_len=9, n_frac=0.2),
+    "one": dict(n_records=1, seed=5),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_decode_block_matches_oracle(fq, sample_fq, name):
+    text = sample_fq if CASES[name] is None else make_fastq(**CASES[name])
+    enc = 1 if name == "ragged_N_phred64" else 0
+    fqz = O.compress(text, batch_records=10 ** 9)            # oracle-encoded block
+    assert fq.compress.decode_block(fqz[10:], 2, enc) == text
+    block, _ = fq.compress.encode_block(text, enc)            # GPU-encoded block
+    assert fq.compress.decode_block(block, 2, enc) == text
+
+
+def test_entropy_decode_matches_oracle(fq):
+    rng = np.random.default_rng(11)
+    p = np.array([0.7] + [0.3 / 255] * 255)
+    cases = [b"\x00" * 50000, bytes(rng.integers(0, 256, 40000, dtype=np.uint8)),
+             bytes(rng.choice(256, 100000, p=p).astype(np.uint8)),
+             bytes(np.minimum(rng.geometric(0.5, 120000) - 1, 60).astype(np.uint8))]
+    for n in [1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 16383, 16384, 16385]:
+        cases.append(bytes(rng.choice([0, 1, 2, 255, 254, 7], n, p=[.6, .15, .1, .1, .03, .02]).astype(np.uint8)))
+    for i, data in enumerate(cases):
+        frame = O.entropy_encode(data)
+        assert fq.compress.entropy_decode(frame, len(data)) == data, "case %d" % i
+    # garbage is refused, not decoded
+    frame = bytearray(O.entropy_encode(cases[2]))
+    with pytest.raises(fq.FqzError):
+        fq.compress.entropy_decode(bytes(frame[:-3]), len(cases[2]))
+
+
+def test_roundtrip_texts_from_reference_tests(fq):
+    import json, os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+    for text in kat["roundtrip_texts"]["cases"]:
+        t = text.encode("latin-1")
+        z = fq.compress.Compress(t)
+        assert z == O.compress(t)                              # same bytes as the oracle pipeline
+        assert fq.compress.Decompress(z) == t
+        assert O.decompress(z) == t
+    assert fq.compress.Compress(b"").hex() == "46515a0002a086010000"   # App. B-7
+    assert fq.compress.Decompress(fq.compress.Compress(b"")) == b""
+
+
+def test_multi_block_files_and_options(fq):
+    seq, qual = b"ACGT" * 38, b"efgh" * 38
+    t = b"".join(b"@SEQ_%d\n%s\n+\n%s\n" % (i, seq, qual) for i in range(500))
+    z = fq.compress.Compress(t, fq.Options(100, 4))
+    assert z[:10].hex() == "46515a000264000000" + "02"          # BlockSize lands in the header, Phred64 flag set
+    assert fq.compress.Decompress(z, fq.DecompressOptions(4)) == t
+    # a file of many blocks written by the oracle (multi-block path the reference tests never reach)
+    t2 = make_fastq(900, seed=8, min_len=50, max_len=120, n_frac=0.02, plus_payload=True)
+    z2 = O.compress(t2, batch_records=64, workers=3)
+    assert fq.compress.Decompress(z2) == t2
+
+
+def test_v1_container_and_errors(fq):
+    text = b"@SEQ_1\nACGTACGT\n+\nIIIIIIII\n"
+    recs, n = O.parse_all(text)
+    streams, _ = O.split_block(text, recs, 1, 0)
+    comp = [O.entropy_encode(streams[k]) for k in (0, 1, 2, 4, 5)]
+    fh = bytes.fromhex("46515a00") + bytes([1]) + (1).to_bytes(4, "little") + b"\x00"
+    bh = b"".join(x.to_bytes(4, "little") for x in [1] + [len(c) for c in comp] + [8, 8])
+    assert fq.compress.Decompress(fh + bh + b"".join(comp)) == text
+    with pytest.raises(fq.FqzError, match="unsupported file version"):
+        fq.compress.Decompress(bytes.fromhex("46515a00") + bytes([3]) + bytes(5))
+    with pytest.raises(fq.FqzError, match="invalid magic"):
+        fq.compress.Decompress(b"XYZ\x00" + bytes(6))
+    z = fq.compress.Compress(text)
+    with pytest.raises(fq.FqzError):
+        fq.compress.Decompress(z[:-1])
+    with pytest.raises(fq.FqzError):
+        fq.compress.Decompress(z[:20])
+
+
+def test_long_read_and_lossy_bases(fq):
+    seq = bytearray(b"ACGT" * 17500)
+    seq[100] = ord("N")
+    t = b"@SEQ_LONG\n" + bytes(seq) + b"\n+\n" + b"I" * 70000 + b"\n"
+    assert fq.compress.Decompress(fq.compress.Compress(t)) == t
+    t = b"@x\nacgtnRY.\n+\nIIIIIIII\n@e\n\n+\n\n"
+    assert fq.compress.Decompress(fq.compress.Compress(t)) == b"@x\nACGTNNNN\n+\nIIIIIIII\n@e\n\n+\n\n"
+
+
+def test_encoder_primitives_match_reference_tables(fq):
+    import json, os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+    E = fq.encoder
+    for c in kat["delta_encode"]["cases"]:
+        assert list(E.DeltaEncode(bytearray(c["in"]))) == c["out"]
+    for c in kat["delta_decode"]["cases"]:
+        assert list(E.DeltaDecode(bytearray(c["in"]))) == c["out"]
+    for c in kat["normalize"]["cases"]:
+        assert list(E.NormalizeQuality(bytearray(c["in"].encode("latin-1")), c["enc"])) == c["out"]
+        assert bytes(E.DenormalizeQuality(bytearray(c["out"]), c["enc"])) == c["in"].encode("latin-1")
+    for c in kat["detect_encoding"]["cases"]:
+        assert E.DetectEncoding([x.encode("latin-1") for x in c["in"]]) == c["enc"], c
+    for c in kat["n_positions"]["cases"]:
+        assert E.PackBases(c["seq"].encode())[1] == c["npos"]
+    for c in kat["case_folding"]["cases"]:
+        p, n = E.PackBases(c["seq"].encode())
+        assert E.UnpackBases(p, n, len(c["seq"])) == c["decoded"].encode()
+    for c in kat["packed_bytes"]["cases"]:
+        assert E.PackBases(c["seq"].encode())[0].hex() == c["hex"]
+    a = kat["append_semantics"]
+    dst, npos = bytearray(), []
+    E.AppendPackedBases(dst, a["first"].encode(), npos)
+    assert npos == []
+    npos2 = []
+    E.AppendPackedBases(dst, a["second"].encode(), npos2)
+    assert len(dst) == a["total_packed"] and npos2 == a["second_npos"]
+    assert E.PackBases(b"") == (None, None)
+    rng = np.random.default_rng(5)
+    s = bytes(rng.choice(np.frombuffer(b"ACGTNacgtn", dtype=np.uint8), 70001))
+    got = E.PackBases(s)
+    want = O.pack_bases(s)
+    assert got[0] == want[0] and got[1] == want[1]
+    q = bytes(rng.integers(33, 74, 5000, dtype=np.uint8))
+    assert bytes(E.DeltaDecode(E.DeltaEncode(bytearray(q)))) == q
+    assert bytes(E.DeltaEncode(bytearray(q))) == O.delta_encode(q)

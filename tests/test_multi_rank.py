@@ -1,0 +1,84 @@
+"""N>1 path on CPU: world_size-2 gloo run of the block-offset exchange, checked against the oracle's
+single-process file (each rank 'encodes' its shard with the oracle; the assembled file must be identical)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from fastq_gen import make_fastq
+
+RPB = 50
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, text, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fastqpacker_amd.sharding import block_offsets_allgather, shard_records
+    recs, n = O.parse_all(text)
+    r0, cnt = shard_records(n, RPB, rank, world)
+    start = recs[r0].hdr_off - 1 if cnt else len(text)
+    end = (recs[r0 + cnt].hdr_off - 1) if r0 + cnt < n else len(text)
+    shard = text[start:end]
+    fqz = O.compress(shard, batch_records=RPB)[10:] if cnt else b""
+    # split the shard's body into blocks by walking the headers
+    lens, pos = [], 0
+    while pos < len(fqz):
+        sizes = [int.from_bytes(fqz[pos + 4 * i: pos + 4 * i + 4], "little") for i in range(9)]
+        blk = 36 + sum(sizes[1:7])
+        lens.append(blk)
+        pos += blk
+    offs, total, allsz = block_offsets_allgather(lens, max_blocks=16)
+    # positional writes into a shared file (pwrite in any order)
+    fd = os.open(out_path, os.O_RDWR)
+    pos = 0
+    for o, l in zip(offs, lens):
+        os.pwrite(fd, fqz[pos:pos + l], o)
+        pos += l
+    if rank == 0:
+        os.pwrite(fd, O.compress(text, batch_records=RPB)[:10], 0)
+    os.close(fd)
+    dist.barrier()
+    if rank == 0:
+        assert total == len(O.compress(text, batch_records=RPB))
+        assert int(allsz.sum()) + 10 == total
+    dist.destroy_process_group()
+
+
+def test_two_rank_offset_exchange(tmp_path):
+    text = make_fastq(430, seed=12, min_len=60, max_len=150, n_frac=0.01)
+    want = O.compress(text, batch_records=RPB)
+    path = str(tmp_path / "out.fqz")
+    with open(path, "wb") as f:
+        f.truncate(len(want))
+    mp.spawn(_worker, args=(2, _free_port(), text, path), nprocs=2, join=True)
+    got = open(path, "rb").read()
+    assert got == want
+    assert O.decompress(got) == text
+
+
+def test_shard_records_covers_everything():
+    from fastqpacker_amd.sharding import shard_records
+    for total in (0, 1, 99, 100, 101, 1234):
+        for world in (1, 2, 3, 8):
+            spans = [shard_records(total, 100, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == total
+            pos = 0
+            for r0, c in spans:
+                if c:
+                    assert r0 == pos
+                    pos += c
+                    assert r0 % 100 == 0
