@@ -95,7 +95,7 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     EncState &e = c->enc;
-    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.partials};
+    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.partials, &e.stamps};
     for (DevBuf *b : eb) b->release();
     e.h_info.release(); e.h_plans.release();
     DecState &d = c->dec;
@@ -237,6 +237,13 @@ extern "C" int fqz_decode_batch_dev(fqz_ctx *ctx, const uint8_t *d_blocks, size_
     int rc = fqz_decode_batch_launch(ctx, d_blocks, n_bytes, version, qual_encoding, d_out, out_cap, stream);
     if (rc) return rc;
     return fqz_decode_batch_finish(ctx, res);
+}
+
+// Diagnostic only (FQZ_DBG_STAMPS=1): s_memtime stamps of k_entropy's phases, 16 x u64 per chunk.
+extern "C" int fqz_debug_get_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_chunks, size_t *n_chunks)
+{
+    if (!ctx || !out || !n_chunks) return FQZ_E_ARG;
+    return fqz_enc_get_stamps(ctx, out, max_chunks, n_chunks);
 }
 
 extern "C" int fqz_debug_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_t stream_len[6])

@@ -77,6 +77,7 @@ struct EncState {
     DevBuf slots;     // chunk_cap * FQZ_SLOT
     DevBuf csize;     // u32[chunk_cap+1] -> exclusive prefix
     DevBuf partials;  // scan partial sums
+    DevBuf stamps;    // diagnostic s_memtime stamps (FQZ_DBG_STAMPS)
     PinnedBuf h_info; // EncInfo
     PinnedBuf h_plans;
 };
@@ -153,6 +154,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
                    uint8_t *d_out, size_t out_cap, hipStream_t stream);
 int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uint64_t *block_len, size_t max_blocks);
 int fqz_enc_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_t stream_len[6]);
+int fqz_enc_get_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_chunks, size_t *n_chunks);
 // fqz_decode.hip
 int fqz_dec_launch(fqz_ctx *ctx, const uint8_t *d_blocks, size_t n_bytes, uint8_t version, int qual_encoding, uint8_t *d_out,
                    size_t out_cap, hipStream_t stream);

@@ -13,7 +13,9 @@
 // block of the batch; no host round trip until the result struct is read back.
 #include "fqz_ctx.h"
 #include "fqz_device.h"
+#include "fqz_entropy_dev.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 // ===========================================================================
@@ -307,53 +309,72 @@ __global__ void k_plan2(EncInfo *info, const uint32_t *E, uint32_t estride, Bloc
 }
 
 // ===========================================================================
-// K1/K2 sequence stream: 2-bit pack + N count (sequence.go:139-184)
-// one wave per record; a lane packs 4 bases per step
+// K1..K4 the record loop of compressBlockWithBuffers (compress.go:474-520), two kernels:
+//   k_split_seq : 2-bit pack + N count                      (sequence.go:139-184)
+//   k_split_rest: quality delta, headers, plus, lengths, N positions (compress.go:495-519, quality.go:53-103)
+// A wave owns 64 consecutive records: every lane first fetches the metadata of "its" record with
+// coalesced loads (line starts as one uint4, the scanned offsets, the block plan), then the wave walks
+// the 64 records with all lanes on one record, the metadata broadcast through v_readlane (SGPR index).
+// That leaves one dependent global round trip per record (the text itself) instead of four.
 // ===========================================================================
+#define RL(v, i) __builtin_amdgcn_readlane((int)(v), (i))
+
 __global__ __launch_bounds__(256) void k_split_seq(const uint8_t *text, const uint32_t *ls, EncInfo *info, uint32_t *E, uint32_t estride,
                                                    const BlockPlan *plans, uint32_t rpb, uint8_t *arena)
 {
-    uint32_t n_rec = info->n_rec;
-    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    const uint32_t n_rec = info->n_rec;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
     const uint32_t *Eseq = E + (size_t)S_SEQ * estride, *Equal = E + (size_t)S_QUAL * estride;
-    for (uint32_t r = wave; r < n_rec; r += nwaves) {
-        uint32_t b = r / rpb;
-        const BlockPlan *p = &plans[b];
-        uint32_t L = Equal[r + 1] - Equal[r];
-        const uint8_t *src = text + ls[4 * r + 1];
-        uint8_t *dst = arena + p->a_off[S_SEQ] + (Eseq[r] - Eseq[p->rec0]);
-        uint32_t nn = 0, beyond = 0;
-        for (uint32_t i = lane; 4 * i < L; i += WAVE) {
-            // the sequence line is followed by "\n+...\n<L quality bytes>": a 4-byte read never leaves the text
-            uint32_t x = load_u32_unaligned(src + 4 * i);
-            uint32_t have = L - 4 * i;
-            uint32_t in_read = 0x80808080u;
-            if (have < 4) { x &= (1u << (8 * have)) - 1; in_read >>= 8 * (4 - have); } // bytes past the read pack as 0
-            uint32_t valid = acgt_mask(x);
-            uint32_t invalid = ~valid & in_read;
-            dst[i] = (uint8_t)pack4(x, valid);
-            if (invalid) {
-                if (4 * i + 3 < FQZ_MAX_SEQUENCE_LENGTH) nn += __popc(invalid);
-                else {
-                    for (uint32_t j = 0; j < 4; j++)
-                        if (invalid & (0x80u << (8 * j))) { if (4 * i + j < FQZ_MAX_SEQUENCE_LENGTH) nn++; else beyond = 1; }
+    uint32_t *Enpos = E + (size_t)S_NPOS * estride;
+    const uint32_t n_groups = (n_rec + 63) >> 6;
+    for (uint32_t g = wave; g < n_groups; g += nwaves) {
+        const uint32_t r = g * 64 + lane;
+        uint32_t m_src = 0, m_len = 0, m_dst = 0;
+        if (r < n_rec) {
+            const BlockPlan *p = &plans[r / rpb];
+            m_src = ls[4 * r + 1];
+            m_len = Equal[r + 1] - Equal[r];
+            m_dst = p->a_off[S_SEQ] + (Eseq[r] - Eseq[p->rec0]);
+        }
+        uint32_t my_nn = 0, my_err = 0;
+        const int cnt = (int)(n_rec - g * 64 < 64 ? n_rec - g * 64 : 64);
+        for (int i = 0; i < cnt; i++) {
+            const uint32_t L = (uint32_t)RL(m_len, i);
+            const uint8_t *src = text + (uint32_t)RL(m_src, i);
+            uint8_t *dst = arena + (uint32_t)RL(m_dst, i);
+            uint32_t nn = 0, beyond = 0;
+            for (uint32_t k = lane; 4 * k < L; k += WAVE) {
+                // the sequence line is followed by "\n+...\n<L quality bytes>": a 4-byte read never leaves the text
+                uint32_t x = load_u32_unaligned(src + 4 * k);
+                uint32_t have = L - 4 * k;
+                uint32_t in_read = 0x80808080u;
+                if (have < 4) { x &= (1u << (8 * have)) - 1; in_read >>= 8 * (4 - have); } // bytes past the read pack as 0
+                uint32_t valid = acgt_mask(x);
+                uint32_t invalid = ~valid & in_read;
+                dst[k] = (uint8_t)pack4(x, valid);
+                if (invalid) {
+                    if (4 * k + 3 < FQZ_MAX_SEQUENCE_LENGTH) nn += __popc(invalid);
+                    else {
+                        for (uint32_t j = 0; j < 4; j++)
+                            if (invalid & (0x80u << (8 * j))) { if (4 * k + j < FQZ_MAX_SEQUENCE_LENGTH) nn++; else beyond = 1; }
+                    }
                 }
             }
+            // N's are rare: skip the reductions when the whole wave saw none
+            if (__ballot(nn | beyond)) {
+                nn = wave_sum(nn);
+                beyond = wave_sum(beyond);
+                if (lane == (uint32_t)i) { my_nn = nn; my_err = beyond; }
+            }
         }
-        nn = wave_sum(nn);
-        beyond = wave_sum(beyond);
-        if (lane == 0) {
-            if (beyond) report_error(info, r, 4, FQZ_E_LONG_N);  // compress.go:477-488
-            if (nn > 65535u) { report_error(info, r, 5, FQZ_E_FIELD_WRAP); nn = 0; }
-            E[(size_t)S_NPOS * estride + r] = 2 + 2 * nn;
+        if (r < n_rec) {
+            if (my_err) report_error(info, r, 4, FQZ_E_LONG_N);  // compress.go:477-488
+            if (my_nn > 65535u) { report_error(info, r, 5, FQZ_E_FIELD_WRAP); my_nn = 0; }
+            Enpos[r] = 2 + 2 * my_nn;
         }
     }
 }
 
-// ===========================================================================
-// K3/K4 quality delta, headers, plus payloads, lengths, N positions
-// (compress.go:495-519, quality.go:53-103)
-// ===========================================================================
 __device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
 {
     for (uint32_t i = lane; i < n; i += WAVE) dst[i] = src[i];
@@ -362,67 +383,77 @@ __device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src
 __global__ __launch_bounds__(256) void k_split_rest(const uint8_t *text, const uint32_t *ls, const EncInfo *info, const uint32_t *E,
                                                     uint32_t estride, const BlockPlan *plans, uint32_t rpb, uint8_t *arena, uint8_t *npos_arena)
 {
-    uint32_t n_rec = info->n_rec, qoff = info->qual_off;
-    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    const uint32_t n_rec = info->n_rec, qoff = info->qual_off;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
     const uint32_t *Equal = E + (size_t)S_QUAL * estride, *Ehdr = E + (size_t)S_HDR * estride;
     const uint32_t *Eplus = E + (size_t)S_PLUS * estride, *Enpos = E + (size_t)S_NPOS * estride;
-    for (uint32_t r = wave; r < n_rec; r += nwaves) {
-        uint32_t b = r / rpb;
-        const BlockPlan *p = &plans[b];
-        uint32_t r0 = p->rec0;
-        uint32_t L = Equal[r + 1] - Equal[r];
-        // ---- quality: q'[0] = q[0]-off, q'[i] = q[i]-q[i-1]  (delta restarts per record)
-        {
-            const uint8_t *q = text + ls[4 * r + 3];
-            uint8_t *dst = arena + p->a_off[S_QUAL] + (Equal[r] - Equal[r0]);
-            for (uint32_t base = 0; base < L; base += 4 * WAVE) {
-                uint32_t i = base + 4 * lane;
-                uint32_t x = 0, have = 0;
-                if (i < L) {
-                    have = L - i < 4 ? L - i : 4;
-                    if (have == 4) x = load_u32_unaligned(q + i);
-                    else for (uint32_t j = 0; j < have; j++) x |= (uint32_t)q[i + j] << (8 * j);
+    const uint32_t n_groups = (n_rec + 63) >> 6;
+    for (uint32_t g = wave; g < n_groups; g += nwaves) {
+        const uint32_t r = g * 64 + lane;
+        // per-lane metadata of record r
+        uint32_t s_hdr = 0, s_seq = 0, s_plus = 0, s_qual = 0, L = 0, H = 0, P = 0, NN = 0;
+        uint32_t d_qual = 0, d_hdr = 0, d_plus = 0, d_npos = 0;
+        if (r < n_rec) {
+            const uint4 l4 = *(const uint4 *)(ls + 4 * (size_t)r); // starts of the record's four lines
+            s_hdr = l4.x + 1; s_seq = l4.y; s_plus = l4.z + 1; s_qual = l4.w;
+            const BlockPlan *p = &plans[r / rpb];
+            const uint32_t r0 = p->rec0;
+            uint32_t eq = Equal[r], eh = Ehdr[r], ep = Eplus[r], en = Enpos[r];
+            L = Equal[r + 1] - eq; H = Ehdr[r + 1] - eh - 2; P = Eplus[r + 1] - ep - 2; NN = (Enpos[r + 1] - en - 2) >> 1;
+            d_qual = p->a_off[S_QUAL] + (eq - Equal[r0]);
+            d_hdr = p->a_off[S_HDR] + (eh - Ehdr[r0]);
+            d_plus = p->a_off[S_PLUS] + (ep - Eplus[r0]);
+            d_npos = p->a_off[S_NPOS] + (en - Enpos[r0]);
+            // ---- length: u32 L (one coalesced store per lane)
+            *(uint32_t *)(arena + p->a_off[S_LEN] + 4 * (r - r0)) = L;
+            // ---- record prefixes: u16 H, u16 P, u16 N count
+            uint8_t *dh = arena + d_hdr, *dp = arena + d_plus, *dn = npos_arena + d_npos;
+            dh[0] = (uint8_t)H; dh[1] = (uint8_t)(H >> 8);
+            dp[0] = (uint8_t)P; dp[1] = (uint8_t)(P >> 8);
+            dn[0] = (uint8_t)NN; dn[1] = (uint8_t)(NN >> 8);
+        }
+        const int cnt = (int)(n_rec - g * 64 < 64 ? n_rec - g * 64 : 64);
+        for (int i = 0; i < cnt; i++) {
+            const uint32_t Li = (uint32_t)RL(L, i);
+            // ---- quality: q'[0] = q[0]-off, q'[k] = q[k]-q[k-1]  (delta restarts per record)
+            {
+                const uint8_t *q = text + (uint32_t)RL(s_qual, i);
+                uint8_t *dst = arena + (uint32_t)RL(d_qual, i);
+                for (uint32_t base = 0; base < Li; base += 4 * WAVE) {
+                    uint32_t k = base + 4 * lane;
+                    uint32_t x = 0, have = 0;
+                    if (k < Li) {
+                        have = Li - k < 4 ? Li - k : 4;
+                        if (have == 4) x = load_u32_unaligned(q + k);
+                        else for (uint32_t j = 0; j < have; j++) x |= (uint32_t)q[k + j] << (8 * j);
+                    }
+                    uint32_t prev = __shfl_up(x >> 24, 1, WAVE);
+                    if (lane == 0) prev = base ? q[base - 1] : qoff;
+                    uint32_t d = sub_bytes(x, (x << 8) | (prev & 0xFF));
+                    if (have == 4) store_u32_unaligned(dst + k, d);
+                    else for (uint32_t j = 0; j < have; j++) dst[k + j] = (uint8_t)(d >> (8 * j));
                 }
-                uint32_t prev = __shfl_up(x >> 24, 1, WAVE);
-                if (lane == 0) prev = base ? q[base - 1] : qoff;
-                uint32_t d = sub_bytes(x, (x << 8) | (prev & 0xFF));
-                if (have == 4) store_u32_unaligned(dst + i, d);
-                else for (uint32_t j = 0; j < have; j++) dst[i + j] = (uint8_t)(d >> (8 * j));
             }
-        }
-        // ---- header: u16 H | bytes (without '@')
-        {
-            uint32_t H = Ehdr[r + 1] - Ehdr[r] - 2;
-            uint8_t *dst = arena + p->a_off[S_HDR] + (Ehdr[r] - Ehdr[r0]);
-            if (lane == 0) { dst[0] = (uint8_t)H; dst[1] = (uint8_t)(H >> 8); }
-            wave_copy_bytes(dst + 2, text + ls[4 * r] + 1, H, lane);
-        }
-        // ---- plus payload: u16 P | bytes (without '+')
-        {
-            uint32_t P = Eplus[r + 1] - Eplus[r] - 2;
-            uint8_t *dst = arena + p->a_off[S_PLUS] + (Eplus[r] - Eplus[r0]);
-            if (lane == 0) { dst[0] = (uint8_t)P; dst[1] = (uint8_t)(P >> 8); }
-            wave_copy_bytes(dst + 2, text + ls[4 * r + 2] + 1, P, lane);
-        }
-        // ---- length: u32 L
-        if (lane == 0) *(uint32_t *)(arena + p->a_off[S_LEN] + 4 * (r - r0)) = L;
-        // ---- N positions: u16 count | u16 positions (ascending, < 65536)
-        {
-            uint32_t nn = (Enpos[r + 1] - Enpos[r] - 2) >> 1;
-            uint8_t *dst = npos_arena + p->a_off[S_NPOS] + (Enpos[r] - Enpos[r0]);
-            if (lane == 0) { dst[0] = (uint8_t)nn; dst[1] = (uint8_t)(nn >> 8); }
-            if (nn) {
-                const uint8_t *sq = text + ls[4 * r + 1];
-                uint32_t limit = L < FQZ_MAX_SEQUENCE_LENGTH ? L : FQZ_MAX_SEQUENCE_LENGTH, run = 0;
+            // ---- header and plus payload bytes (without '@' / '+')
+            wave_copy_bytes(arena + (uint32_t)RL(d_hdr, i) + 2, text + (uint32_t)RL(s_hdr, i), (uint32_t)RL(H, i), lane);
+            {
+                const uint32_t Pi = (uint32_t)RL(P, i);
+                if (Pi) wave_copy_bytes(arena + (uint32_t)RL(d_plus, i) + 2, text + (uint32_t)RL(s_plus, i), Pi, lane);
+            }
+            // ---- N positions: u16 positions (ascending, < 65536)
+            if (RL(NN, i)) {
+                const uint8_t *sq = text + (uint32_t)RL(s_seq, i);
+                uint8_t *dst = npos_arena + (uint32_t)RL(d_npos, i);
+                uint32_t limit = Li < FQZ_MAX_SEQUENCE_LENGTH ? Li : FQZ_MAX_SEQUENCE_LENGTH, run = 0;
                 for (uint32_t base = 0; base < limit; base += WAVE) {
-                    uint32_t i = base + lane;
+                    uint32_t k = base + lane;
                     bool inv = false;
-                    if (i < limit) inv = (acgt_mask((uint32_t)sq[i] * 0x01010101u) & 0x80u) == 0;
+                    if (k < limit) inv = (acgt_mask((uint32_t)sq[k] * 0x01010101u) & 0x80u) == 0;
                     unsigned long long m = __ballot(inv);
                     if (inv) {
-                        uint32_t k = run + __popcll(m & ((1ull << lane) - 1));
-                        dst[2 + 2 * k] = (uint8_t)i;
-                        dst[3 + 2 * k] = (uint8_t)(i >> 8);
+                        uint32_t w = run + __popcll(m & ((1ull << lane) - 1));
+                        dst[2 + 2 * w] = (uint8_t)k;
+                        dst[3 + 2 * w] = (uint8_t)(k >> 8);
                     }
                     run += __popcll(m);
                 }
@@ -437,224 +468,14 @@ __global__ __launch_bounds__(256) void k_split_rest(const uint8_t *text, const u
 // The construction is the deterministic "FQZ-H1" profile specified in DESIGN.md
 // and restated on the CPU in oracle/fqz_entropy.c; outputs are byte-identical.
 // ===========================================================================
-struct HufScratch {          // lives in the (not yet used) output staging buffer
-    uint32_t cnt[512];
-    uint16_t parent[512];
-    uint8_t depth[512];
-    uint8_t l[256];          // lengths in sorted order
-    uint8_t w[256];          // weights in symbol order
-    uint8_t tree[272];       // Huffman_Tree_Description
-    uint16_t state_table[64];
-    uint8_t table_symbol[64];
-};
-
-struct LdsBitW { uint8_t *p; unsigned long long acc; int nb; };
-__device__ __forceinline__ void bw_add(LdsBitW &b, uint32_t v, int n)
-{
-    b.acc |= (unsigned long long)v << b.nb;
-    b.nb += n;
-    while (b.nb >= 8) { *b.p++ = (uint8_t)b.acc; b.acc >>= 8; b.nb -= 8; }
-}
-
-// returns compressed size; 0 = not compressible; 1 = single symbol (mirrors oracle fse_compress_weights)
-__device__ uint32_t fse_compress_weights_dev(const uint8_t *w, int n, uint8_t *dst, HufScratch *sc)
-{
-    if (n <= 1) return 0;
-    int cnt[13], maxw = 0, maxc = 0;
-    for (int s = 0; s < 13; s++) cnt[s] = 0;
-    for (int i = 0; i < n; i++) { int x = w[i]; cnt[x]++; maxw = x > maxw ? x : maxw; }
-    for (int s = 0; s <= maxw; s++) maxc = cnt[s] > maxc ? cnt[s] : maxc;
-    if (maxc == n) return 1;
-    if (maxc == 1) return 0;
-    int table_log = 6;
-    {
-        int max_bits_src = highbit32_d((uint32_t)(n - 1)) - 2;
-        int min_bits_src = highbit32_d((uint32_t)n) + 1;
-        int min_bits_sym = highbit32_d((uint32_t)maxw) + 2;
-        int min_bits = min_bits_src < min_bits_sym ? min_bits_src : min_bits_sym;
-        if (max_bits_src < table_log) table_log = max_bits_src;
-        if (min_bits > table_log) table_log = min_bits;
-        if (table_log < 5) table_log = 5;
-        if (table_log > 6) table_log = 6;
-    }
-    int table_size = 1 << table_log;
-    int norm[13], present = 0, largest = 0;
-    for (int s = 0; s < 13; s++) norm[s] = 0;
-    for (int s = 0; s <= maxw; s++) {
-        if (cnt[s]) present++;
-        if (cnt[s] > cnt[largest]) largest = s;
-    }
-    int R = table_size - present, given = 0;
-    for (int s = 0; s <= maxw; s++)
-        if (cnt[s]) { int e = (cnt[s] * R) / n; norm[s] = 1 + e; given += e; }
-    norm[largest] += R - given;
-
-    uint8_t *op = dst;
-    {
-        uint32_t bits = 0;
-        int bc = 0;
-        int remaining = table_size + 1, threshold = table_size, nb = table_log + 1;
-        int sym = 0, alphabet = maxw + 1, prev0 = 0;
-        bits += (uint32_t)(table_log - 5) << bc; bc += 4;
-        while (sym < alphabet && remaining > 1) {
-            if (prev0) {
-                int start = sym;
-                while (sym < alphabet && !norm[sym]) sym++;
-                if (sym == alphabet) break;
-                while (sym >= start + 3) { start += 3; bits += 3u << bc; bc += 2; }
-                bits += (uint32_t)(sym - start) << bc; bc += 2;
-                if (bc > 16) { *op++ = (uint8_t)bits; *op++ = (uint8_t)(bits >> 8); bits >>= 16; bc -= 16; }
-            }
-            {
-                int c = norm[sym++];
-                int max = (2 * threshold - 1) - remaining;
-                remaining -= c;
-                c++;
-                if (c >= threshold) c += max;
-                bits += (uint32_t)c << bc;
-                bc += nb;
-                bc -= (c < max);
-                prev0 = (c == 1);
-                while (remaining < threshold) { nb--; threshold >>= 1; }
-            }
-            if (bc > 16) { *op++ = (uint8_t)bits; *op++ = (uint8_t)(bits >> 8); bits >>= 16; bc -= 16; }
-        }
-        if (bc > 0) *op++ = (uint8_t)bits;
-        if (bc > 8) *op++ = (uint8_t)(bits >> 8);
-    }
-    int delta_nb[13], delta_find[13];
-    {
-        int cumul[14];
-        cumul[0] = 0;
-        for (int s = 1; s <= maxw + 1; s++) cumul[s] = cumul[s - 1] + norm[s - 1];
-        int step = (table_size >> 1) + (table_size >> 3) + 3, mask = table_size - 1, pos = 0;
-        for (int s = 0; s <= maxw; s++)
-            for (int i = 0; i < norm[s]; i++) { sc->table_symbol[pos] = (uint8_t)s; pos = (pos + step) & mask; }
-        for (int u = 0; u < table_size; u++) { int s = sc->table_symbol[u]; sc->state_table[cumul[s]++] = (uint16_t)(table_size + u); }
-        int total = 0;
-        for (int s = 0; s <= maxw; s++) {
-            if (norm[s] == 0) { delta_nb[s] = ((table_log + 1) << 16) - table_size; delta_find[s] = 0; }
-            else if (norm[s] == 1) { delta_nb[s] = (table_log << 16) - table_size; delta_find[s] = total - 1; total++; }
-            else {
-                int max_bits_out = table_log - highbit32_d((uint32_t)(norm[s] - 1));
-                int min_state_plus = norm[s] << max_bits_out;
-                delta_nb[s] = (max_bits_out << 16) - min_state_plus;
-                delta_find[s] = total - norm[s];
-                total += norm[s];
-            }
-        }
-    }
-    LdsBitW bw = {op, 0ull, 0};
-    uint32_t st0 = 0, st1 = 0;
-    int in0 = 0, in1 = 0;
-    for (int i = n - 1; i >= 0; i--) {
-        int s = w[i];
-        uint32_t &st = (i & 1) ? st1 : st0;
-        int &inited = (i & 1) ? in1 : in0;
-        if (!inited) {
-            uint32_t nb_out = (uint32_t)(delta_nb[s] + (1 << 15)) >> 16;
-            uint32_t value = (nb_out << 16) - (uint32_t)delta_nb[s];
-            st = sc->state_table[(value >> nb_out) + delta_find[s]];
-            inited = 1;
-        } else {
-            uint32_t nb_out = (st + (uint32_t)delta_nb[s]) >> 16;
-            bw_add(bw, st & ((1u << nb_out) - 1), (int)nb_out);
-            st = sc->state_table[(st >> nb_out) + delta_find[s]];
-        }
-    }
-    bw_add(bw, st1 & (uint32_t)(table_size - 1), table_log);
-    bw_add(bw, st0 & (uint32_t)(table_size - 1), table_log);
-    bw_add(bw, 1, 1);
-    if (bw.nb) { *bw.p++ = (uint8_t)bw.acc; }
-    return (uint32_t)(bw.p - dst);
-}
-
-// Serial (one lane) table build: code lengths -> weights -> tree description.
-// keys: 256 sorted ascending (count<<8|sym), zeros first.  Returns tree size (0 = give up -> raw block),
-// writes nbits[256] and *max_bits.
-__device__ uint32_t huf_build_dev(const uint32_t *keys, int n_active, uint8_t *nbits, int *max_bits_out, HufScratch *sc)
-{
-    const uint32_t *key = keys + (256 - n_active);
-    int n = n_active;
-    for (int i = 0; i < n; i++) sc->cnt[i] = key[i] >> 8;
-    int li = 0, ih = n, it = n;
-    for (int k = 0; k < n - 1; k++) {
-        int a, b;
-        if (li < n && (ih >= it || sc->cnt[li] <= sc->cnt[ih])) a = li++; else a = ih++;
-        if (li < n && (ih >= it || sc->cnt[li] <= sc->cnt[ih])) b = li++; else b = ih++;
-        sc->cnt[it] = sc->cnt[a] + sc->cnt[b];
-        sc->parent[a] = sc->parent[b] = (uint16_t)it;
-        it++;
-    }
-    int root = 2 * n - 2;
-    sc->depth[root] = 0;
-    for (int v = root - 1; v >= 0; v--) sc->depth[v] = (uint8_t)(sc->depth[sc->parent[v]] + 1);
-    int maxd = 0;
-    for (int i = 0; i < n; i++) { sc->l[i] = sc->depth[i]; maxd = sc->l[i] > maxd ? sc->l[i] : maxd; }
-    if (maxd > FQZ_HUF_MAX_BITS) {
-        int K = 0;
-        for (int i = 0; i < n; i++) {
-            if (sc->l[i] > FQZ_HUF_MAX_BITS) sc->l[i] = FQZ_HUF_MAX_BITS;
-            K += 1 << (FQZ_HUF_MAX_BITS - sc->l[i]);
-        }
-        while (K > (1 << FQZ_HUF_MAX_BITS)) {
-            int best = -1;
-            for (int i = 0; i < n; i++)
-                if (sc->l[i] < FQZ_HUF_MAX_BITS && (best < 0 || sc->l[i] > sc->l[best])) best = i;
-            sc->l[best]++;
-            K -= 1 << (FQZ_HUF_MAX_BITS - sc->l[best]);
-        }
-        int slack = (1 << FQZ_HUF_MAX_BITS) - K;
-        while (slack > 0) {
-            for (int i = n - 1; i >= 0 && slack > 0; i--)
-                while (sc->l[i] > 1 && (1 << (FQZ_HUF_MAX_BITS - sc->l[i])) <= slack) {
-                    slack -= 1 << (FQZ_HUF_MAX_BITS - sc->l[i]);
-                    sc->l[i]--;
-                }
-        }
-        maxd = 0;
-        for (int i = 0; i < n; i++) maxd = sc->l[i] > maxd ? sc->l[i] : maxd;
-    }
-    for (int s = 0; s < 256; s++) nbits[s] = 0;
-    for (int i = 0; i < n; i++) nbits[key[i] & 0xFF] = sc->l[i];
-    *max_bits_out = maxd;
-
-    // Huffman_Tree_Description (oracle fqzo_huf_write_tree)
-    int max_sym = 255;
-    while (max_sym > 0 && !nbits[max_sym]) max_sym--;
-    int nw = max_sym;
-    for (int s = 0; s < nw; s++) sc->w[s] = nbits[s] ? (uint8_t)(maxd + 1 - nbits[s]) : 0;
-    uint32_t h = fse_compress_weights_dev(sc->w, nw, sc->tree + 1, sc);
-    if (h > 1 && h < (uint32_t)nw / 2) {
-        sc->tree[0] = (uint8_t)h;
-        return h + 1;
-    }
-    if (nw > 128) return 0;
-    sc->tree[0] = (uint8_t)(128 + (nw - 1));
-    sc->w[nw] = 0;
-    for (int i = 0; i < nw; i += 2) sc->tree[i / 2 + 1] = (uint8_t)((sc->w[i] << 4) + sc->w[i + 1]);
-    return (uint32_t)((nw + 1) / 2) + 1;
-}
-
-#define OUT_WORDS ((FQZ_CHUNK + 64) / 4)
-
 __global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const BlockPlan *plans, const uint8_t *arena, const uint8_t *npos_arena,
-                                                 uint8_t *slots, uint32_t *csize)
+                                                 uint8_t *slots, uint32_t *csize, int dbg_stop, unsigned long long *stamps)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[FQZ_CHUNK / 4 + 4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_out[OUT_WORDS];
-    __shared__ uint32_t s_hist[4 * 256];
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[256];
-    __shared__ __attribute__((aligned(16))) uint32_t s_sorted[256];
-    __shared__ uint32_t s_ctab[256];
-    __shared__ uint8_t s_nbits[256];
-    __shared__ uint32_t s_misc[32];
-    // s_misc: 0 src offset, 1 m, 2 last, 3 stream id, 4 n_active, 5 mode (0 raw,1 rle,2 huf), 6 tree size, 7 max bits,
-    //         8..11 stream bit totals, 12 total bytes, 13 max count
-
+    __shared__ __attribute__((aligned(16))) EntropyLds S;
     const uint32_t chunk = blockIdx.x;
     if (chunk >= info->n_chunks) return;
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    if (stamps) { stamps += (size_t)chunk * 16; if (t == 0) stamps[0] = __builtin_amdgcn_s_memtime(); }
 
     if (t == 0) {
         uint32_t nb = info->n_blocks, lo = 0, hi = nb;
@@ -665,26 +486,27 @@ __global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const Bloc
             uint32_t nch = (p->len[k] + FQZ_CHUNK - 1) / FQZ_CHUNK;
             if (nch && chunk >= p->chunk_base[k] && chunk < p->chunk_base[k] + nch) s = k;
         }
+        if (stamps) stamps[15] = (unsigned long long)s;
         uint32_t c = chunk - p->chunk_base[s];
         uint32_t off = c * FQZ_CHUNK;
         uint32_t m = p->len[s] - off < FQZ_CHUNK ? p->len[s] - off : FQZ_CHUNK;
-        s_misc[0] = p->a_off[s] + off;
-        s_misc[1] = m;
-        s_misc[2] = (off + m == p->len[s]);
-        s_misc[3] = (uint32_t)s;
+        S.misc[0] = p->a_off[s] + off;
+        S.misc[1] = m;
+        S.misc[2] = (off + m == p->len[s]);
+        S.misc[3] = (uint32_t)s;
     }
-    for (uint32_t i = t; i < 4 * 256; i += 256) s_hist[i] = 0;
-    if (t < 4) s_chunk[FQZ_CHUNK / 4 + t] = 0;
+    uint32_t *hist_all = lds_hist(S);
+    for (uint32_t i = t; i < 4 * 256; i += 256) hist_all[i] = 0;
+    if (t < 4) S.chunk[FQZ_CHUNK / 4 + t] = 0;
     __syncthreads();
-    const uint32_t m = s_misc[1], last = s_misc[2];
-    const uint8_t *src = (s_misc[3] == S_NPOS ? npos_arena : arena) + s_misc[0]; // 16-byte aligned
-    uint8_t *slot = slots + (size_t)chunk * FQZ_SLOT;
+    const uint32_t m = S.misc[1], last = S.misc[2];
+    const uint8_t *src = (S.misc[3] == S_NPOS ? npos_arena : arena) + S.misc[0]; // 16-byte aligned
 
     // ---- load chunk into LDS + per-wave histograms ---------------------------------
     // Skewed data (quality deltas are mostly 0) would serialise LDS atomics on one bin: for each
     // byte column the wave first peels off every lane that agrees with its first lane (one add).
     {
-        uint32_t *hist = s_hist + wave * 256;
+        uint32_t *hist = hist_all + wave * 256;
         for (uint32_t q = t; q < FQZ_CHUNK / 16; q += 256) {
             uint32_t off = q * 16;
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -695,7 +517,7 @@ __global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const Bloc
                 for (uint32_t k = 0; k < have; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            *(uint4 *)&s_chunk[q * 4] = v;
+            *(uint4 *)&S.chunk[q * 4] = v;
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (uint32_t k = 0; k < 16; k++) {
@@ -704,7 +526,7 @@ __global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const Bloc
                 unsigned long long am = __ballot(act);
                 if (am) {
                     int first = __ffsll((long long)am) - 1;
-                    uint32_t cand = __shfl(byte, first, WAVE);
+                    uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)byte, first); // uniform lane index: v_readlane, no LDS round trip
                     unsigned long long same = __ballot(act && byte == cand);
                     if (lane == (uint32_t)first) atomicAdd(&hist[cand], (uint32_t)__popcll(same));
                     if (act && byte != cand) atomicAdd(&hist[byte], 1u);
@@ -713,213 +535,7 @@ __global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const Bloc
         }
     }
     __syncthreads();
-    // ---- merge histograms, classify -------------------------------------------------
-    {
-        uint32_t c = s_hist[t] + s_hist[256 + t] + s_hist[512 + t] + s_hist[768 + t];
-        s_keys[t] = c ? ((c << 8) | t) : 0u;
-        unsigned long long act = __ballot(c != 0);
-        uint32_t mx = c;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_xor(mx, d, WAVE); mx = o > mx ? o : mx; }
-        if (lane == 0) { s_misc[8 + wave] = (uint32_t)__popcll(act); s_misc[16 + wave] = mx; }
-    }
-    __syncthreads();
-    if (t == 0) {
-        uint32_t n_active = s_misc[8] + s_misc[9] + s_misc[10] + s_misc[11];
-        uint32_t mx = max(max(s_misc[16], s_misc[17]), max(s_misc[18], s_misc[19]));
-        s_misc[4] = n_active;
-        s_misc[13] = mx;
-        uint32_t mode = 2;
-        if (n_active == 1) mode = 1;                              // RLE block
-        else if (m < 64) mode = 0;                                // raw
-        else if ((unsigned long long)mx * 200ull <= m) mode = 0;  // near-flat histogram
-        s_misc[5] = mode;
-    }
-    __syncthreads();
-    uint32_t mode = s_misc[5];
-    const uint32_t n_active = s_misc[4];
-
-    if (mode == 2) {
-        // ---- rank sort of the 256 keys (ascending; distinct when non-zero, ties among zeros by index)
-        {
-            uint32_t my = s_keys[t], rank = 0;
-            for (uint32_t j = 0; j < 256; j += 4) {
-                uint4 k4 = *(const uint4 *)&s_keys[j];
-                rank += (k4.x < my) || (k4.x == my && j + 0 < t);
-                rank += (k4.y < my) || (k4.y == my && j + 1 < t);
-                rank += (k4.z < my) || (k4.z == my && j + 2 < t);
-                rank += (k4.w < my) || (k4.w == my && j + 3 < t);
-            }
-            s_sorted[rank] = my;
-        }
-        __syncthreads();
-        // ---- serial table build on one lane (scratch aliases the output staging buffer)
-        HufScratch *sc = (HufScratch *)s_out;
-        if (t == 0) {
-            int max_bits = 0;
-            uint32_t ts = huf_build_dev(s_sorted, (int)n_active, s_nbits, &max_bits, sc);
-            s_misc[6] = ts;
-            s_misc[7] = (uint32_t)max_bits;
-            if (!ts) s_misc[5] = 0;
-        }
-        __syncthreads();
-        mode = s_misc[5];
-    }
-    if (mode == 2) {
-        // ---- canonical codes (RFC 8878 4.2.1.3): from the longest length up, symbol order inside a length
-        const uint32_t max_bits = s_misc[7];
-        {
-            uint32_t nb = s_nbits[t];
-            // per-length counts via ballots; s_hist reused: [len] = count, [16+len] = first code
-            if (t < 32) s_hist[t] = 0;
-            __syncthreads();
-            uint32_t my_rank = 0;
-            for (uint32_t len = 1; len <= max_bits; len++) {
-                unsigned long long bm = __ballot(nb == len);
-                if (nb == len) my_rank = (uint32_t)__popcll(bm & ((1ull << lane) - 1));
-                if (lane == 0 && bm) s_hist[64 + wave * 16 + len] = (uint32_t)__popcll(bm);
-                else if (lane == 0) s_hist[64 + wave * 16 + len] = 0;
-            }
-            __syncthreads();
-            if (t == 0) {
-                uint32_t minv = 0;
-                for (uint32_t len = max_bits; len > 0; len--) {
-                    uint32_t cnt = s_hist[64 + len] + s_hist[80 + len] + s_hist[96 + len] + s_hist[112 + len];
-                    s_hist[16 + len] = minv;
-                    minv = (minv + cnt) >> 1;
-                }
-            }
-            __syncthreads();
-            uint32_t code = 0;
-            if (nb) {
-                uint32_t before = 0;
-                for (uint32_t w2 = 0; w2 < wave; w2++) before += s_hist[64 + w2 * 16 + nb];
-                code = s_hist[16 + nb] + before + my_rank;
-            }
-            s_ctab[t] = code | (nb << 16);
-        }
-        __syncthreads();
-        // copy the tree description out of the scratch before the staging buffer is cleared
-        uint32_t tree_size = s_misc[6];
-        uint8_t tree_byte = 0;
-        HufScratch *sc = (HufScratch *)s_out;
-        if (t < tree_size) tree_byte = sc->tree[t];
-        uint8_t tree_byte2 = 0;
-        if (t + 256 < tree_size) tree_byte2 = sc->tree[t + 256];
-        __syncthreads();
-        for (uint32_t i = t; i < OUT_WORDS; i += 256) s_out[i] = 0;
-        __syncthreads();
-
-        // ---- pass 1: bits per lane, per stream (wave w encodes stream w)
-        const uint32_t nstreams = m >= 256 ? 4 : 1;
-        const uint32_t seg = nstreams == 4 ? (m + 3) / 4 : m;
-        const uint32_t seg_base = wave * seg;
-        uint32_t seg_len = 0;
-        if (wave < nstreams) seg_len = (wave == nstreams - 1) ? m - seg_base : seg;
-        // symbols per lane: multiple of 4 with an odd dword count -> conflict-free LDS byte reads
-        uint32_t per = ((seg_len + 63) / 64 + 3) & ~3u;
-        if (((per >> 2) & 1) == 0) per += 4;
-        uint32_t a = lane * per, b = a + per;
-        if (a > seg_len) a = seg_len;
-        if (b > seg_len) b = seg_len;
-        const uint8_t *cb = (const uint8_t *)s_chunk + seg_base;
-        uint32_t my_bits = 0;
-        for (uint32_t j = a; j < b; j++) my_bits += s_ctab[cb[j]] >> 16;
-        uint32_t incl = wave_incl_scan(my_bits);
-        uint32_t tot_bits = __shfl(incl, 63, WAVE);
-        uint32_t bit_off = tot_bits - incl; // bits of all higher lanes = symbols written before mine
-        if (lane == 0) s_misc[8 + wave] = tot_bits;
-        __syncthreads();
-        // ---- sizes, raw fallback, headers (one lane; before any atomicOr touches those words)
-        if (t == 0) {
-            uint32_t ssz[4] = {0, 0, 0, 0}, total_streams = 0;
-            for (uint32_t k = 0; k < nstreams; k++) { ssz[k] = (s_misc[8 + k] >> 3) + 1; total_streams += ssz[k]; }
-            uint32_t lit_csize = tree_size + (nstreams == 4 ? 6 : 0) + total_streams;
-            uint32_t lh = m < 1024 ? 3 : (m < 16384 ? 4 : 5);
-            uint32_t content = lh + lit_csize + 1;
-            if (content >= m) s_misc[5] = 0;
-            else {
-                uint8_t *o = (uint8_t *)s_out;
-                uint32_t bh = (last & 1) | (2u << 1) | (content << 3);
-                o[0] = (uint8_t)bh; o[1] = (uint8_t)(bh >> 8); o[2] = (uint8_t)(bh >> 16);
-                if (lh == 3) {
-                    uint32_t v = 2u | ((nstreams == 4 ? 1u : 0u) << 2) | (m << 4) | (lit_csize << 14);
-                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16);
-                } else if (lh == 4) {
-                    uint32_t v = 2u | (2u << 2) | (m << 4) | (lit_csize << 18);
-                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
-                } else {
-                    uint32_t v = 2u | (3u << 2) | (m << 4) | (lit_csize << 22);
-                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
-                    o[7] = (uint8_t)(lit_csize >> 10);
-                }
-                uint32_t pos = 3 + lh + tree_size;
-                if (nstreams == 4) {
-                    for (int k = 0; k < 3; k++) { o[pos + 2 * k] = (uint8_t)ssz[k]; o[pos + 2 * k + 1] = (uint8_t)(ssz[k] >> 8); }
-                    pos += 6;
-                }
-                for (uint32_t k = 0; k < 4; k++) { s_misc[8 + k] = pos; pos += ssz[k]; } // stream start bytes
-                o[pos] = 0;                                                                // Number_of_Sequences = 0
-                s_misc[12] = pos + 1;
-                s_misc[14] = 3 + lh; // tree offset
-            }
-        }
-        __syncthreads();
-        mode = s_misc[5];
-        if (mode == 2) {
-            uint8_t *o = (uint8_t *)s_out;
-            uint32_t tree_off = s_misc[14];
-            if (t < tree_size) o[tree_off + t] = tree_byte;
-            if (t + 256 < tree_size) o[tree_off + t + 256] = tree_byte2;
-            __syncthreads();
-            // ---- pass 2: symbols last-to-first, LSB-first bit packing (HUF_compress1X order)
-            if (wave < nstreams) {
-                uint32_t P0 = 8 * s_misc[8 + wave] + bit_off;
-                uint32_t word = P0 >> 5;
-                uint32_t fill = P0 & 31;
-                unsigned long long acc = 0;
-                for (uint32_t j = b; j-- > a;) {
-                    uint32_t e = s_ctab[cb[j]];
-                    acc |= (unsigned long long)(e & 0xFFFF) << fill;
-                    fill += e >> 16;
-                    if (fill >= 32) { atomicOr(&s_out[word++], (uint32_t)acc); acc >>= 32; fill -= 32; }
-                }
-                if (lane == 0) { // end mark above the first symbol's code
-                    acc |= 1ull << fill;
-                    fill += 1;
-                    if (fill >= 32) { atomicOr(&s_out[word++], (uint32_t)acc); acc >>= 32; fill -= 32; }
-                }
-                if (fill) atomicOr(&s_out[word], (uint32_t)acc);
-            }
-            __syncthreads();
-            uint32_t total = s_misc[12];
-            uint32_t *slot32 = (uint32_t *)slot;
-            for (uint32_t i = t; i < (total + 3) / 4; i += 256) slot32[i] = s_out[i];
-            if (t == 0) csize[chunk] = total;
-            return;
-        }
-    }
-    if (mode == 1) { // RLE block: 3-byte header + the byte
-        if (t == 0) {
-            uint32_t bh = (last & 1) | (1u << 1) | (m << 3);
-            uint32_t b0 = ((const uint8_t *)s_chunk)[0];
-            *(uint32_t *)slot = (bh & 0xFFFFFF) | (b0 << 24);
-            csize[chunk] = 4;
-        }
-        return;
-    }
-    // raw block: 3-byte header + m bytes, composed dword-wise from the LDS copy
-    {
-        uint32_t bh = (last & 1) | (0u << 1) | (m << 3);
-        uint32_t total = 3 + m;
-        uint32_t *slot32 = (uint32_t *)slot;
-        for (uint32_t i = t; i < (total + 3) / 4; i += 256) {
-            uint32_t lo = i ? s_chunk[i - 1] : (bh << 8), hi = s_chunk[i];
-            // out bytes 4i..4i+3 = header/chunk bytes 4i-3..4i
-            slot32[i] = __builtin_amdgcn_alignbyte(hi, lo, 1);
-        }
-        if (t == 0) csize[chunk] = total;
-    }
+    entropy_encode_chunk(S, m, last, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
 }
 
 // ===========================================================================
@@ -1016,6 +632,32 @@ __global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const Bloc
 // ===========================================================================
 // host side
 // ===========================================================================
+static int fqz_dbg_stop()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("FQZ_DBG_STOP"); v = e ? atoi(e) : 0; }
+    return v;
+}
+// FQZ_DBG_STAMPS=1: per-chunk s_memtime stamps (16 x u64 per chunk) for phase timing; dumped by fqz_debug_stamps
+static unsigned long long *fqz_dbg_stamps(EncState &e)
+{
+    static int on = -1;
+    if (on < 0) { const char *v = getenv("FQZ_DBG_STAMPS"); on = v ? atoi(v) : 0; }
+    if (!on) return nullptr;
+    if (e.stamps.ensure((size_t)e.chunk_cap * 16 * 8)) return nullptr;
+    (void)hipMemset(e.stamps.p, 0, (size_t)e.chunk_cap * 16 * 8);
+    return e.stamps.as<unsigned long long>();
+}
+int fqz_enc_get_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_chunks, size_t *n_chunks)
+{
+    EncState &e = ctx->enc;
+    const EncInfo *hi = e.h_info.as<EncInfo>();
+    if (!hi || !e.stamps.p) return FQZ_E_ARG;
+    size_t n = hi->n_chunks < max_chunks ? hi->n_chunks : max_chunks;
+    HIP_TRY(hipMemcpy(out, e.stamps.p, n * 16 * 8, hipMemcpyDeviceToHost));
+    *n_chunks = n;
+    return FQZ_OK;
+}
 static inline uint32_t grid_for_waves(uint32_t n_items)
 {
     // one wave per item, 4 waves per workgroup, capped: the kernels grid-stride
@@ -1095,11 +737,11 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     }
     launch_scan(ctx, "scan_records", st, E, &info->n_rec, 0, e.rec_cap, 4, estride, partials, pmax); // seq, qual, hdr, plus
     PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(64), 0, st, info, E, estride, plans, rpb, e.arena_cap));
-    PROF(ctx, st, "k_split_seq", hipLaunchKernelGGL(k_split_seq, dim3(grid_for_waves(e.rec_cap)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena));
+    PROF(ctx, st, "k_split_seq", hipLaunchKernelGGL(k_split_seq, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena));
     launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
     PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
-    PROF(ctx, st, "k_split_rest", hipLaunchKernelGGL(k_split_rest, dim3(grid_for_waves(e.rec_cap)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena, npos));
-    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize));
+    PROF(ctx, st, "k_split_rest", hipLaunchKernelGGL(k_split_rest, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena, npos));
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, 1, e.chunk_cap + 1, partials, pmax);
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_out, out_cap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out));
@@ -1212,7 +854,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     uint32_t *csize = e.csize.as<uint32_t>();
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, 0);
     hipLaunchKernelGGL(k_single_plan, dim3(1), dim3(64), 0, st, info, plans, (uint32_t)n);
-    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize));
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
     launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks, 1, chunks + 1, e.partials.as<uint32_t>(), chunks / SCAN_TILE + 2);
     hipLaunchKernelGGL(k_single_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_dst, cap);
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, d_dst));

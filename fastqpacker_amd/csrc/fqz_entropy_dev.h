@@ -1,0 +1,596 @@
+// fqz_entropy_dev.h — device side of the entropy stage: one 256-thread workgroup turns a <= 16 KiB
+// chunk that already sits in LDS (with its per-wave histograms) into one zstd block.
+//
+// Replaces zstd.Encoder.EncodeAll (internal/compress/compress.go:523-528) with the deterministic
+// "FQZ-H1" construction of DESIGN.md §4; byte-identical to oracle/fqz_entropy.c.
+//
+// Work split inside the workgroup:
+//   all 256 lanes : histogram merge, rank sort, leaf depths, weights, canonical codes, bit packing
+//   lane 0        : the two-queue Huffman merge (n_active-1 dependent steps)
+//   wave 0, scalar: the FSE state chain over the weights (inherently sequential): tables live in
+//                   VGPR lanes and are indexed with v_readlane, state and bit buffer live in SGPRs
+#pragma once
+#include "fqz_device.h"
+
+#define OUT_WORDS ((FQZ_CHUNK + 64) / 4)
+
+struct HufScratch {          // aliases the (not yet used) output staging buffer
+    uint32_t cnt[512];       // node weights: leaves 0..n-1 (sorted), internal n..2n-2
+    uint16_t parent[512];
+    uint8_t l[256];          // code lengths in sorted order
+    uint8_t tree[272];       // Huffman_Tree_Description
+    uint16_t state_table[64];
+    uint32_t fse_bits[64];   // FSE bitstream of the weights (dword aligned)
+    uint32_t nc_bits[8];     // FSE NCount header bits
+};
+
+struct EntropyLds {
+    uint32_t chunk[FQZ_CHUNK / 4 + 4];   // the chunk, zero padded
+    uint32_t out[OUT_WORDS];             // HufScratch during the table build, then the zstd block
+    uint32_t keys[256];
+    uint32_t sorted[256];
+    uint32_t ctab[256];                  // code | nbits << 16
+    uint32_t cc[128];                    // canonical-code scratch
+    uint32_t misc[32];
+    uint8_t nbits[256];
+    uint8_t w[256];
+};
+// per-wave histograms alias out[] beyond the HufScratch area; dead before out[] is cleared
+#define HIST_WORD_OFF 2048
+__device__ __forceinline__ uint32_t *lds_hist(EntropyLds &S) { return S.out + HIST_WORD_OFF; }
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane)); }
+
+// ---------------------------------------------------------------------------------------------
+// FSE compression of the Huffman weights, executed by wave 0 (all 64 lanes, uniform control flow).
+// w: S.w[0..nw) ; returns the compressed size (uniform): 0 = not compressible, 1 = single symbol.
+// Output bytes land in sc->tree[1..].  Mirrors oracle fse_compress_weights().
+// Everything on the sequential path is wave-uniform so that hipcc keeps it on the scalar unit:
+// counts come from ballots, per-position transforms are looked up in parallel beforehand, the
+// state tables sit in VGPR lanes (v_readlane with an SGPR index) and output dwords are collected
+// with v_writelane.
+// ---------------------------------------------------------------------------------------------
+struct UBits { // LSB-first bit writer with uniform state; dword k of the stream ends up in lane k of `v`
+    unsigned long long acc;
+    int nb;
+    int wpos;
+    int v;
+};
+__device__ __forceinline__ void ub_put(UBits &b, uint32_t val, int n)
+{
+    b.acc |= (unsigned long long)val << b.nb;
+    b.nb += n;
+    if (b.nb >= 32) {
+        b.v = ((int)lane_id() == b.wpos) ? (int)(uint32_t)b.acc : b.v; // v_cndmask: no branch
+        b.wpos++;
+        b.acc >>= 32;
+        b.nb -= 32;
+    }
+}
+__device__ __forceinline__ uint32_t ub_close(UBits &b) // returns total bits; flushes the partial dword
+{
+    uint32_t total = (uint32_t)b.wpos * 32u + (uint32_t)b.nb;
+    if (b.nb) { b.v = ((int)lane_id() == b.wpos) ? (int)(uint32_t)b.acc : b.v; b.wpos++; }
+    return total;
+}
+
+__device__ __forceinline__ uint32_t fse_weights_wave0(EntropyLds &S, HufScratch *sc, int n_in)
+{
+    const int n = __builtin_amdgcn_readfirstlane(n_in);
+    const int lane = (int)lane_id();
+    int wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { int idx = lane + 64 * j; wv[j] = idx < n ? (int)S.w[idx] : 255; }
+    int cnt[13];
+#pragma unroll
+    for (int v = 0; v < 13; v++) {
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) c += (int)__popcll(__ballot(wv[j] == v));
+        cnt[v] = c;
+    }
+    int maxw = 0, maxc = 0, present = 0, largest = 0;
+#pragma unroll
+    for (int v = 0; v < 13; v++) { if (cnt[v]) { maxw = v; present++; } }
+#pragma unroll
+    for (int v = 0; v < 13; v++) { if (cnt[v] > maxc) { maxc = cnt[v]; largest = v; } } // first maximum = lowest symbol
+    if (n <= 2) return 0;
+    if (maxc == n) return 1;
+    if (maxc == 1) return 0;
+    int table_log = 6;
+    {
+        int max_bits_src = highbit32_d((uint32_t)(n - 1)) - 2;
+        int min_bits_src = highbit32_d((uint32_t)n) + 1;
+        int min_bits_sym = highbit32_d((uint32_t)maxw) + 2;
+        int min_bits = min_bits_src < min_bits_sym ? min_bits_src : min_bits_sym;
+        if (max_bits_src < table_log) table_log = max_bits_src;
+        if (min_bits > table_log) table_log = min_bits;
+        if (table_log < 5) table_log = 5;
+        if (table_log > 6) table_log = 6;
+    }
+    const int table_size = 1 << table_log;
+    int norm[13], cumul[14];
+    {
+        int R = table_size - present, given = 0;
+#pragma unroll
+        for (int v = 0; v < 13; v++) {
+            int e = cnt[v] ? (cnt[v] * R) / n : 0;
+            norm[v] = cnt[v] ? 1 + e : 0;
+            given += e;
+        }
+#pragma unroll
+        for (int v = 0; v < 13; v++) if (v == largest) norm[v] += R - given;
+        cumul[0] = 0;
+#pragma unroll
+        for (int v = 0; v < 13; v++) cumul[v + 1] = cumul[v] + norm[v];
+    }
+    // ---- FSE_writeNCount as a plain LSB-first bit stream (same bytes as the 16-bit-flush original)
+    UBits nc = {0ull, 0, 0, 0};
+    {
+        int remaining = table_size + 1, threshold = table_size, nb = table_log + 1, prev0 = 0, run = 0;
+        ub_put(nc, (uint32_t)(table_log - 5), 4);
+#pragma unroll
+        for (int v = 0; v < 13; v++) {
+            if (v <= maxw && remaining > 1) {
+                if (prev0 && norm[v] == 0) { run++; }
+                else {
+                    if (prev0) { // close the zero run: 2-bit repeat codes (run <= 11 here)
+                        if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
+                        if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
+                        if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
+                        ub_put(nc, (uint32_t)run, 2);
+                        run = 0;
+                    }
+                    int c = norm[v];
+                    int max = (2 * threshold - 1) - remaining;
+                    remaining -= c;
+                    c++;
+                    if (c >= threshold) c += max;
+                    ub_put(nc, (uint32_t)c, nb - (c < max ? 1 : 0));
+                    prev0 = (c == 1);
+#pragma unroll
+                    for (int q = 0; q < 7; q++) if (remaining < threshold) { nb--; threshold >>= 1; }
+                }
+            }
+        }
+    }
+    const uint32_t nc_bytes = (ub_close(nc) + 7) >> 3;
+    // ---- FSE_buildCTable: lane u owns table position u
+    const int mask = table_size - 1;
+    const int inv = table_size == 32 ? 7 : 3; // step^-1 mod table_size (step 23: 23*7 = 161; step 43: 43*3 = 129)
+    {
+        int my_sym = 0;
+        int k = (lane * inv) & mask; // spread order index of position `lane`: pos_k = (k*step) & mask
+#pragma unroll
+        for (int v = 0; v < 13; v++) if (k >= cumul[v] && k < cumul[v + 1]) my_sym = v;
+        int rank = 0, base = 0;
+#pragma unroll
+        for (int v = 0; v < 13; v++) {
+            unsigned long long bm = __ballot(lane < table_size && my_sym == v);
+            if (my_sym == v) { rank = (int)__popcll(bm & ((1ull << lane) - 1)); base = cumul[v]; }
+        }
+        if (lane < table_size) sc->state_table[base + rank] = (uint16_t)(table_size + lane);
+    }
+    wave_lds_sync();
+    const int st_v = lane < table_size ? (int)sc->state_table[lane] : 0; // lane j holds stateTable[j]
+    int dnb_v = 0, dfs_v = 0;                                            // lane s holds the transform of symbol s
+#pragma unroll
+    for (int v = 0; v < 13; v++) {
+        if (lane == v) {
+            int nv = norm[v];
+            if (nv == 0) { dnb_v = ((table_log + 1) << 16) - table_size; dfs_v = 0; }
+            else if (nv == 1) { dnb_v = (table_log << 16) - table_size; dfs_v = cumul[v] - 1; }
+            else {
+                int mbo = table_log - highbit32_d((uint32_t)(nv - 1));
+                dnb_v = (mbo << 16) - (nv << mbo);
+                dfs_v = cumul[v] - nv;
+            }
+        }
+    }
+    // per-position transforms, looked up in parallel (lane k, register j <-> position 64*j + k)
+    int dnbp[4], dfsp[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { dnbp[j] = __shfl(dnb_v, wv[j] & 15, WAVE); dfsp[j] = __shfl(dfs_v, wv[j] & 15, WAVE); }
+
+    // ---- the state chain, scalar: symbols from the last to the first, state1 = even, state2 = odd positions.
+    // The chain only advances the two states and records (bits, nbits) of every step in the lane that owns
+    // the position; the bit stream is assembled afterwards in parallel.
+    int rec[4] = {0, 0, 0, 0};  // bits | nbits << 16 of position 64*j + lane
+    uint32_t st0 = 0, st1 = 0;  // st0: even positions (CState1), st1: odd positions (CState2)
+    {
+        // FSE_initCState2 for the last two positions: no output
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = n - 1 - q, jj = i >> 6, l = i & 63;
+            int dnb = 0, dfs = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (jj == j) { dnb = __builtin_amdgcn_readlane(dnbp[j], l); dfs = __builtin_amdgcn_readlane(dfsp[j], l); }
+            uint32_t nb_out = (uint32_t)(dnb + (1 << 15)) >> 16;
+            uint32_t value = (nb_out << 16) - (uint32_t)dnb;
+            uint32_t ns = (uint32_t)__builtin_amdgcn_readlane(st_v, (int)((value >> nb_out) + (uint32_t)dfs));
+            if (i & 1) st1 = ns; else st0 = ns;
+        }
+    }
+    const int top = n - 3; // highest position that emits bits
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+        int hi = top - 64 * j;
+        if (hi > 63) hi = 63;
+        for (int l = hi; l >= 0; l--) { // uniform trip count: scalar loop; 64*j is even, so parity(position) = parity(l)
+            int dnb = __builtin_amdgcn_readlane(dnbp[j], l);
+            int dfs = __builtin_amdgcn_readlane(dfsp[j], l);
+            uint32_t st = (l & 1) ? st1 : st0;
+            uint32_t nb_out = (st + (uint32_t)dnb) >> 16;
+            uint32_t bits = st & ((1u << nb_out) - 1);
+            uint32_t ns = (uint32_t)__builtin_amdgcn_readlane(st_v, (int)((st >> nb_out) + (uint32_t)dfs));
+            rec[j] = (lane == l) ? (int)(bits | (nb_out << 16)) : rec[j];
+            if (l & 1) st1 = ns; else st0 = ns;
+        }
+    }
+    // ---- parallel assembly: position p is emitted after every position > p (p <= top), so its bit offset is
+    // the number of bits of all higher positions
+    sc->fse_bits[lane] = 0;
+    wave_lds_sync();
+    uint32_t above = 0; // bits of the registers j' > j
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+        uint32_t nbj = (uint32_t)rec[j] >> 16, bits = (uint32_t)rec[j] & 0xFFFF;
+        uint32_t incl = wave_incl_scan(nbj);
+        uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t off = above + (tot - incl);
+        if (nbj) {
+            uint32_t w = off >> 5, sh = off & 31;
+            atomicOr(&sc->fse_bits[w], bits << sh);
+            if (sh + nbj > 32) atomicOr(&sc->fse_bits[w + 1], bits >> (32 - sh));
+        }
+        above += tot;
+    }
+    // tail: flush state2, then state1, then the end mark
+    uint32_t total_bits = above;
+    if (lane == 0) {
+        unsigned long long tail = (unsigned long long)(st1 & (uint32_t)(table_size - 1)) |
+                                  ((unsigned long long)(st0 & (uint32_t)(table_size - 1)) << table_log) | (1ull << (2 * table_log));
+        uint32_t w = total_bits >> 5, sh = total_bits & 31;
+        atomicOr(&sc->fse_bits[w], (uint32_t)(tail << sh));
+        if (sh + 2 * table_log + 1 > 32) atomicOr(&sc->fse_bits[w + 1], (uint32_t)((tail << sh) >> 32));
+    }
+    total_bits += 2 * (uint32_t)table_log + 1;
+    const uint32_t fse_bytes = (total_bits + 7) >> 3;
+    // ---- NCount bytes, then the FSE stream, into the tree description
+    if (lane < 8) sc->nc_bits[lane] = (uint32_t)nc.v;
+    wave_lds_sync();
+    uint8_t *dst = sc->tree + 1;
+    const uint8_t *nb8 = (const uint8_t *)sc->nc_bits, *fb8 = (const uint8_t *)sc->fse_bits;
+    if ((uint32_t)lane < nc_bytes) dst[lane] = nb8[lane];
+    for (uint32_t i = (uint32_t)lane; i < fse_bytes; i += 64) dst[nc_bytes + i] = fb8[i];
+    return nc_bytes + fse_bytes;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One chunk -> one zstd block.  Preconditions (after a __syncthreads()):
+//   S.chunk holds the m bytes (zero padded to a multiple of 16 + 16), lds_hist(S)[wave*256 + sym]
+//   holds the per-wave byte counts.  All 256 threads call this; they return together.
+// ---------------------------------------------------------------------------------------------
+// dbg_stop > 0 (FQZ_DBG_STOP, timing experiments only): leave after that phase with a dummy 4-byte block
+// stamps != nullptr (FQZ_DBG_STAMPS, diagnostic runs only): lane 0 records s_memtime at every phase boundary
+#define DBG_STOP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime(); \
+                         if (dbg_stop == (k)) { if (threadIdx.x == 0) *csize_out = 4; return; } } while (0)
+__device__ void entropy_encode_chunk(EntropyLds &S, const uint32_t m, const uint32_t last, uint8_t *slot, uint32_t *csize_out, const int dbg_stop = 0,
+                                     unsigned long long *stamps = nullptr)
+{
+    DBG_STOP(1);
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    uint32_t *hist = lds_hist(S);
+    // S.misc: 4 n_active, 5 mode (0 raw, 1 rle, 2 huffman), 6 tree size, 7 max bits, 8..11 per-wave scratch / stream bits,
+    //         12 total bytes, 13 max count, 14 tree offset, 16..19 per-wave scratch, 20 max depth, 21 nw
+    // ---- merge histograms, classify -------------------------------------------------
+    {
+        uint32_t c = hist[t] + hist[256 + t] + hist[512 + t] + hist[768 + t];
+        S.keys[t] = c ? ((c << 8) | t) : 0u;
+        unsigned long long act = __ballot(c != 0);
+        uint32_t sq = wave_sum(c * c); // c <= 16384, the sum of squares <= 2^28
+        if (lane == 0) { S.misc[8 + wave] = (uint32_t)__popcll(act); S.misc[16 + wave] = sq; }
+    }
+    __syncthreads();
+    const uint32_t n_active = S.misc[8] + S.misc[9] + S.misc[10] + S.misc[11];
+    uint32_t mode = 2;
+    {
+        unsigned long long sq = (unsigned long long)S.misc[16] + S.misc[17] + S.misc[18] + S.misc[19];
+        if (n_active == 1) mode = 1;                                          // RLE block
+        else if (m < 64) mode = 0;                                            // raw
+        else if (sq * 230ull <= (unsigned long long)m * m) mode = 0;          // collision entropy >= log2(230) = 7.85 bits: nothing to gain
+    }
+    __syncthreads(); // misc[8..19] are reused below
+
+    HufScratch *sc = (HufScratch *)S.out;
+    uint32_t tree_size = 0, max_bits = 0;
+    DBG_STOP(2);
+    if (mode == 2) {
+        // ---- rank sort of the 256 keys (ascending; distinct when non-zero, ties among zeros by index)
+        {
+            uint32_t my = S.keys[t], rank = 0;
+#pragma unroll 16
+            for (uint32_t j = 0; j < 256; j += 4) {
+                uint4 k4 = *(const uint4 *)&S.keys[j];
+                rank += (k4.x < my) || (k4.x == my && j + 0 < t);
+                rank += (k4.y < my) || (k4.y == my && j + 1 < t);
+                rank += (k4.z < my) || (k4.z == my && j + 2 < t);
+                rank += (k4.w < my) || (k4.w == my && j + 3 < t);
+            }
+            S.sorted[rank] = my;
+        }
+        __syncthreads();
+        DBG_STOP(3);
+        const uint32_t n = n_active;
+        const uint32_t *key = S.sorted + (256 - n);
+        if (t < n) sc->cnt[t] = key[t] >> 8;
+        __syncthreads();
+        // ---- two-queue Huffman merge, leaf preferred on ties (one lane)
+        if (t == 0) {
+            uint32_t li = 0, ih = n, it = n;
+            uint32_t cl = sc->cnt[0], ci = 0; // head weights of the leaf and internal queues
+            for (uint32_t k = 0; k + 1 < n; k++) {
+                uint32_t a, b, ca, cb2;
+                if (li < n && (ih >= it || cl <= ci)) { a = li++; ca = cl; cl = li < n ? sc->cnt[li] : 0; }
+                else { a = ih++; ca = ci; ci = ih < it ? sc->cnt[ih] : 0; }
+                if (li < n && (ih >= it || cl <= ci)) { b = li++; cb2 = cl; cl = li < n ? sc->cnt[li] : 0; }
+                else { b = ih++; cb2 = ci; ci = ih < it ? sc->cnt[ih] : 0; }
+                sc->cnt[it] = ca + cb2;
+                if (ih == it) ci = ca + cb2; // the new node is the head of an empty internal queue
+                sc->parent[a] = (uint16_t)it;
+                sc->parent[b] = (uint16_t)it;
+                it++;
+            }
+        }
+        __syncthreads();
+        // ---- leaf depths: every leaf walks to the root
+        {
+            uint32_t d = 0;
+            if (t < n) {
+                uint32_t v = t, root = 2 * n - 2;
+                while (v != root) { v = sc->parent[v]; d++; }
+                sc->l[t] = (uint8_t)d;
+            }
+            uint32_t mx = d;
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) { uint32_t o = __shfl_xor(mx, s, WAVE); mx = o > mx ? o : mx; }
+            if (lane == 0) S.misc[16 + wave] = mx;
+        }
+        __syncthreads();
+        uint32_t maxd = max(max(S.misc[16], S.misc[17]), max(S.misc[18], S.misc[19]));
+        if (maxd > FQZ_HUF_MAX_BITS) {
+            // ---- length limiting (rare): clamp, repair the Kraft sum in units of 2^-11 (one lane)
+            if (t == 0) {
+                int K = 0;
+                for (uint32_t i = 0; i < n; i++) {
+                    if (sc->l[i] > FQZ_HUF_MAX_BITS) sc->l[i] = FQZ_HUF_MAX_BITS;
+                    K += 1 << (FQZ_HUF_MAX_BITS - sc->l[i]);
+                }
+                while (K > (1 << FQZ_HUF_MAX_BITS)) {
+                    int best = -1;
+                    for (uint32_t i = 0; i < n; i++)
+                        if (sc->l[i] < FQZ_HUF_MAX_BITS && (best < 0 || sc->l[i] > sc->l[best])) best = (int)i;
+                    sc->l[best]++;
+                    K -= 1 << (FQZ_HUF_MAX_BITS - sc->l[best]);
+                }
+                int slack = (1 << FQZ_HUF_MAX_BITS) - K;
+                while (slack > 0) {
+                    for (int i = (int)n - 1; i >= 0 && slack > 0; i--)
+                        while (sc->l[i] > 1 && (1 << (FQZ_HUF_MAX_BITS - sc->l[i])) <= slack) {
+                            slack -= 1 << (FQZ_HUF_MAX_BITS - sc->l[i]);
+                            sc->l[i]--;
+                        }
+                }
+                uint32_t md = 0;
+                for (uint32_t i = 0; i < n; i++) md = sc->l[i] > md ? sc->l[i] : md;
+                S.misc[20] = md;
+            }
+            __syncthreads();
+            maxd = S.misc[20];
+        }
+        max_bits = maxd;
+        DBG_STOP(4);
+        // ---- lengths back to symbol order, weights, highest symbol
+        S.nbits[t] = 0;
+        __syncthreads();
+        if (t < n) S.nbits[key[t] & 0xFF] = sc->l[t];
+        __syncthreads();
+        uint32_t nb = S.nbits[t];
+        DBG_STOP(10);
+        {
+            unsigned long long bm = __ballot(nb != 0);
+            if (lane == 0) S.misc[16 + wave] = bm ? wave * 64 + (63 - (uint32_t)__clzll((long long)bm)) : 0;
+        }
+        __syncthreads();
+        const uint32_t nw = max(max(S.misc[16], S.misc[17]), max(S.misc[18], S.misc[19])); // weights for symbols 0..nw-1
+        S.w[t] = (t < nw && nb) ? (uint8_t)(maxd + 1 - nb) : 0;
+        __syncthreads();
+        DBG_STOP(11);
+        // ---- Huffman_Tree_Description: direct 4-bit weights when they fit, FSE-compressed otherwise
+        if (nw <= 128) {
+            if (t == 0) sc->tree[0] = (uint8_t)(128 + (nw - 1));
+            if (2 * t < nw) sc->tree[1 + t] = (uint8_t)((S.w[2 * t] << 4) + S.w[2 * t + 1]);
+            tree_size = (nw + 1) / 2 + 1;
+        } else {
+            if (wave == 0) {
+                uint32_t h = fse_weights_wave0(S, sc, (int)nw);
+                if (lane == 0) {
+                    uint32_t ts = 0;
+                    if (h > 1 && h < nw / 2) { sc->tree[0] = (uint8_t)h; ts = h + 1; }
+                    S.misc[6] = ts;
+                }
+            }
+            __syncthreads();
+            tree_size = S.misc[6];
+            if (!tree_size) mode = 0; // not representable: raw block
+        }
+    }
+    DBG_STOP(5);
+    if (mode == 2) {
+        // ---- canonical codes (RFC 8878 4.2.1.3): from the longest length up, symbol order inside a length
+        {
+            uint32_t nb = S.nbits[t];
+            uint32_t my_rank = 0;
+            for (uint32_t len = 1; len <= max_bits; len++) {
+                unsigned long long bm = __ballot(nb == len);
+                if (nb == len) my_rank = (uint32_t)__popcll(bm & ((1ull << lane) - 1));
+                if (lane == 0) S.cc[32 + wave * 16 + len] = (uint32_t)__popcll(bm);
+            }
+            __syncthreads();
+            if (t == 0) {
+                uint32_t minv = 0;
+                for (uint32_t len = max_bits; len > 0; len--) {
+                    uint32_t cnt = S.cc[32 + len] + S.cc[48 + len] + S.cc[64 + len] + S.cc[80 + len];
+                    S.cc[len] = minv;
+                    minv = (minv + cnt) >> 1;
+                }
+            }
+            __syncthreads();
+            uint32_t code = 0;
+            if (nb) {
+                uint32_t before = 0;
+                for (uint32_t w2 = 0; w2 < wave; w2++) before += S.cc[32 + w2 * 16 + nb];
+                code = S.cc[nb] + before + my_rank;
+            }
+            S.ctab[t] = code | (nb << 16);
+        }
+        // keep the tree description in registers while the staging buffer is cleared
+        uint8_t tree_byte = t < tree_size ? sc->tree[t] : 0;
+        __syncthreads();
+        for (uint32_t i = t; i < OUT_WORDS; i += 256) S.out[i] = 0;
+        __syncthreads();
+
+        DBG_STOP(6);
+        // ---- pass 1: bits per lane, per stream (wave w encodes stream w)
+        const uint32_t nstreams = m >= 256 ? 4 : 1;
+        const uint32_t seg = nstreams == 4 ? (m + 3) / 4 : m;
+        const uint32_t seg_base = wave * seg;
+        uint32_t seg_len = 0;
+        if (wave < nstreams) seg_len = (wave == nstreams - 1) ? m - seg_base : seg;
+        // symbols per lane: multiple of 4 with an odd dword count -> conflict-free LDS byte reads
+        uint32_t per = ((seg_len + 63) / 64 + 3) & ~3u;
+        if (((per >> 2) & 1) == 0) per += 4;
+        uint32_t a = lane * per, b = a + per;
+        if (a > seg_len) a = seg_len;
+        if (b > seg_len) b = seg_len;
+        const uint8_t *cb = (const uint8_t *)S.chunk + seg_base;
+        uint32_t my_bits = 0;
+        for (uint32_t j = a; j < b; j++) my_bits += S.ctab[cb[j]] >> 16;
+        uint32_t incl = wave_incl_scan(my_bits);
+        uint32_t tot_bits = __shfl(incl, 63, WAVE);
+        uint32_t bit_off = tot_bits - incl; // bits of all higher lanes = symbols written before mine
+        if (lane == 0) S.misc[8 + wave] = tot_bits;
+        __syncthreads();
+        DBG_STOP(7);
+        // ---- sizes, raw fallback, headers (one lane; before any atomicOr touches those words)
+        if (t == 0) {
+            uint32_t ssz[4] = {0, 0, 0, 0}, total_streams = 0;
+            for (uint32_t k = 0; k < nstreams; k++) { ssz[k] = (S.misc[8 + k] >> 3) + 1; total_streams += ssz[k]; }
+            uint32_t lit_csize = tree_size + (nstreams == 4 ? 6 : 0) + total_streams;
+            uint32_t lh = m < 1024 ? 3 : (m < 16384 ? 4 : 5);
+            uint32_t content = lh + lit_csize + 1;
+            if (content >= m) S.misc[5] = 0;
+            else {
+                S.misc[5] = 2;
+                uint8_t *o = (uint8_t *)S.out;
+                uint32_t bh = (last & 1) | (2u << 1) | (content << 3);
+                o[0] = (uint8_t)bh; o[1] = (uint8_t)(bh >> 8); o[2] = (uint8_t)(bh >> 16);
+                if (lh == 3) {
+                    uint32_t v = 2u | ((nstreams == 4 ? 1u : 0u) << 2) | (m << 4) | (lit_csize << 14);
+                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16);
+                } else if (lh == 4) {
+                    uint32_t v = 2u | (2u << 2) | (m << 4) | (lit_csize << 18);
+                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
+                } else {
+                    uint32_t v = 2u | (3u << 2) | (m << 4) | (lit_csize << 22);
+                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
+                    o[7] = (uint8_t)(lit_csize >> 10);
+                }
+                uint32_t pos = 3 + lh + tree_size;
+                if (nstreams == 4) {
+                    for (int k = 0; k < 3; k++) { o[pos + 2 * k] = (uint8_t)ssz[k]; o[pos + 2 * k + 1] = (uint8_t)(ssz[k] >> 8); }
+                    pos += 6;
+                }
+                for (uint32_t k = 0; k < 4; k++) { S.misc[8 + k] = pos; pos += ssz[k]; } // stream start bytes
+                o[pos] = 0;                                                                // Number_of_Sequences = 0
+                S.misc[12] = pos + 1;
+                S.misc[14] = 3 + lh; // tree offset
+            }
+        }
+        __syncthreads();
+        mode = S.misc[5];
+        if (mode == 2) {
+            uint8_t *o = (uint8_t *)S.out;
+            if (t < tree_size) o[S.misc[14] + t] = tree_byte;
+            __syncthreads();
+            // ---- pass 2: symbols last-to-first, LSB-first bit packing (HUF_compress1X order)
+            if (wave < nstreams) {
+                uint32_t P0 = 8 * S.misc[8 + wave] + bit_off;
+                uint32_t word = P0 >> 5;
+                uint32_t fill = P0 & 31;
+                unsigned long long acc = 0;
+                uint32_t j = b;
+                // two symbols per step (<= 22 new bits on top of < 32 pending fit the 64-bit accumulator)
+                for (; j >= a + 2; j -= 2) {
+                    uint32_t e1 = S.ctab[cb[j - 1]], e2 = S.ctab[cb[j - 2]];
+                    acc |= (unsigned long long)(e1 & 0xFFFF) << fill;
+                    fill += e1 >> 16;
+                    acc |= (unsigned long long)(e2 & 0xFFFF) << fill;
+                    fill += e2 >> 16;
+                    atomicOr(&S.out[word], (uint32_t)acc);
+                    uint32_t adv = fill >> 5;            // 0 or 1 whole words completed
+                    acc >>= (adv << 5);
+                    word += adv;
+                    fill &= 31;
+                }
+                if (j > a) {
+                    uint32_t e = S.ctab[cb[j - 1]];
+                    acc |= (unsigned long long)(e & 0xFFFF) << fill;
+                    fill += e >> 16;
+                    atomicOr(&S.out[word], (uint32_t)acc);
+                    uint32_t adv = fill >> 5;
+                    acc >>= (adv << 5);
+                    word += adv;
+                    fill &= 31;
+                }
+                if (lane == 0) { acc |= 1ull << fill; fill += 1; } // end mark above the first symbol's code
+                if (fill) atomicOr(&S.out[word], (uint32_t)acc);
+                if (fill > 32) atomicOr(&S.out[word + 1], (uint32_t)(acc >> 32));
+            }
+            __syncthreads();
+            DBG_STOP(8);
+            uint32_t total = S.misc[12];
+            uint32_t *slot32 = (uint32_t *)slot;
+            for (uint32_t i = t; i < (total + 3) / 4; i += 256) slot32[i] = S.out[i];
+            if (t == 0) *csize_out = total;
+            DBG_STOP(9);
+            return;
+        }
+    }
+    if (mode == 1) { // RLE block: 3-byte header + the byte
+        if (t == 0) {
+            uint32_t bh = (last & 1) | (1u << 1) | (m << 3);
+            uint32_t b0 = ((const uint8_t *)S.chunk)[0];
+            *(uint32_t *)slot = (bh & 0xFFFFFF) | (b0 << 24);
+            *csize_out = 4;
+        }
+        return;
+    }
+    // raw block: 3-byte header + m bytes, composed dword-wise from the LDS copy
+    {
+        uint32_t bh = (last & 1) | (0u << 1) | (m << 3);
+        uint32_t total = 3 + m;
+        uint32_t *slot32 = (uint32_t *)slot;
+        for (uint32_t i = t; i < (total + 3) / 4; i += 256) {
+            uint32_t lo = i ? S.chunk[i - 1] : (bh << 8), hi = S.chunk[i];
+            slot32[i] = __builtin_amdgcn_alignbyte(hi, lo, 1); // out bytes 4i..4i+3 = header/chunk bytes 4i-3..4i
+        }
+        if (t == 0) *csize_out = total;
+    }
+}

@@ -173,6 +173,9 @@ int fqz_decode_batch_finish(fqz_ctx *ctx, fqz_batch_result *res);
  * in/out (capacity in, size out); streams[k] may be NULL to query sizes. */
 int fqz_debug_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_t stream_len[6]);
 
+/* Diagnostic hook (FQZ_DBG_STAMPS=1 in the environment): per-chunk s_memtime stamps of the entropy kernel's phases. */
+int fqz_debug_get_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_chunks, size_t *n_chunks);
+
 /* ---- internal/encoder primitive mirrors (GPU-executed, host buffers) ----- */
 /* encoder.PackBases / AppendPackedBases (sequence.go:58,139): packed gets
  * (n+3)/4 bytes, npos the positions (< 65536) of non-ACGTacgt bytes. */

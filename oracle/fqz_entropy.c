@@ -17,7 +17,7 @@
  *   block  = one per FQZO_CHUNK (16 KiB) bytes of the stream, in order:
  *            RLE block        when all bytes are equal,
  *            Raw block        when m < 64, when the histogram is near-flat
- *                             (max count * 200 <= m) or Huffman does not shrink it,
+ *                             (sum of squared counts * 230 <= m^2) or Huffman does not shrink it,
  *            Compressed block = Huffman-coded literals (1 stream if m < 256,
  *            else 4 streams) + "0 sequences".
  *   empty stream -> 0 bytes (klauspost EncodeAll without WithZeroFrames).
@@ -271,6 +271,12 @@ size_t fqzo_huf_write_tree(const uint8_t nbits[256], int max_bits, uint8_t *dst)
     int nw = max_sym; /* weights for symbols 0..max_sym-1; the last is implied */
     uint8_t w[256];
     for (int s = 0; s < nw; s++) w[s] = nbits[s] ? (uint8_t)(max_bits + 1 - nbits[s]) : 0;
+    if (nw <= 128) { /* direct 4-bit weights whenever they fit: no serial FSE pass on the GPU for ASCII-range alphabets */
+        dst[0] = (uint8_t)(128 + (nw - 1));
+        w[nw] = 0;
+        for (int i = 0; i < nw; i += 2) dst[i / 2 + 1] = (uint8_t)((w[i] << 4) + w[i + 1]);
+        return (size_t)((nw + 1) / 2) + 1;
+    }
     uint8_t tmp[300];
     size_t h = fse_compress_weights(w, nw, tmp);
     if (h > 1 && h < (size_t)nw / 2) {
@@ -278,11 +284,7 @@ size_t fqzo_huf_write_tree(const uint8_t nbits[256], int max_bits, uint8_t *dst)
         memcpy(dst + 1, tmp, h);
         return h + 1;
     }
-    if (nw > 128) return 0;
-    dst[0] = (uint8_t)(128 + (nw - 1));
-    w[nw] = 0;
-    for (int i = 0; i < nw; i += 2) dst[i / 2 + 1] = (uint8_t)((w[i] << 4) + w[i + 1]);
-    return (size_t)((nw + 1) / 2) + 1;
+    return 0; /* more than 128 weights and FSE does not help: the chunk is stored raw */
 }
 
 /* ===================================================================== */
@@ -320,10 +322,11 @@ size_t fqzo_encode_chunk(const uint8_t *src, size_t m, int last, uint8_t *dst)
         return 4;
     }
     if (m < 64) return raw_block(src, m, last, dst);
-    {   /* near-flat histogram (p_max <= 1/200, i.e. >= 7.6 bits/symbol): not worth a table */
-        uint32_t maxc = 0;
-        for (int s = 0; s < 256; s++) if (count[s] > maxc) maxc = count[s];
-        if ((uint64_t)maxc * 200 <= m) return raw_block(src, m, last, dst);
+    {   /* near-flat histogram: collision entropy -log2(sum p^2) >= log2(230) = 7.85 bits bounds the Shannon entropy
+         * from below, so a Huffman table could save < 2 %: store raw (this is what 2-bit packed bases look like) */
+        uint64_t sq = 0;
+        for (int s = 0; s < 256; s++) sq += (uint64_t)count[s] * count[s];
+        if (sq * 230 <= (uint64_t)m * m) return raw_block(src, m, last, dst);
     }
 
     uint8_t nbits[256];
