@@ -187,8 +187,16 @@ def main():
         avg_s = kern[dom][0] / kern[dom][1] / 1e3
         algorithmic = in_bytes + out_bytes  # B_in + B_out per launch
         ach = algorithmic / avg_s / 1e9
+        # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
+        # separately; summary committed under profiles/): static evidence, not re-measured in this process
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")))
+            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": algorithmic, "avg_launch_ms": round(avg_s * 1e3, 4),
                 "pipeline_GBps": round(algorithmic / (sum(v[0] for v in kern.values()) / a.steps / 1e3) / 1e9, 1)}
     out = {
