@@ -503,37 +503,7 @@ __global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const Bloc
     const uint8_t *src = (S.misc[3] == S_NPOS ? npos_arena : arena) + S.misc[0]; // 16-byte aligned
 
     // ---- load chunk into LDS + per-wave histograms ---------------------------------
-    // Skewed data (quality deltas are mostly 0) would serialise LDS atomics on one bin: for each
-    // byte column the wave first peels off every lane that agrees with its first lane (one add).
-    {
-        uint32_t *hist = hist_all + wave * 256;
-        for (uint32_t q = t; q < FQZ_CHUNK / 16; q += 256) {
-            uint32_t off = q * 16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            uint32_t have = off < m ? (m - off < 16 ? m - off : 16) : 0;
-            if (have == 16) v = *(const uint4 *)(src + off);
-            else if (have) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint32_t k = 0; k < have; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            *(uint4 *)&S.chunk[q * 4] = v;
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (uint32_t k = 0; k < 16; k++) {
-                uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
-                bool act = k < have;
-                unsigned long long am = __ballot(act);
-                if (am) {
-                    int first = __ffsll((long long)am) - 1;
-                    uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)byte, first); // uniform lane index: v_readlane, no LDS round trip
-                    unsigned long long same = __ballot(act && byte == cand);
-                    if (lane == (uint32_t)first) atomicAdd(&hist[cand], (uint32_t)__popcll(same));
-                    if (act && byte != cand) atomicAdd(&hist[byte], 1u);
-                }
-            }
-        }
-    }
+    load_chunk_and_histogram(S, src, m);
     __syncthreads();
     entropy_encode_chunk(S, m, last, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
 }

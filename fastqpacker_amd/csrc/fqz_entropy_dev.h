@@ -22,6 +22,11 @@ struct HufScratch {          // aliases the (not yet used) output staging buffer
     uint16_t state_table[64];
     uint32_t fse_bits[64];   // FSE bitstream of the weights (dword aligned)
     uint32_t nc_bits[8];     // FSE NCount header bits
+    int dnb[16], dfs[16];    // FSE symbol transforms (deltaNbBits, deltaFindState)
+    uint32_t start[2][4];    // true start state of every chunk of the two state chains
+    uint32_t fin[2];         // final states (flushed at the end of the stream)
+    uint32_t rec[256];       // bits | nbits << 16 emitted at each weight position
+    uint8_t endmap[2][4][64];// end state of a chunk for every possible start state
 };
 
 struct EntropyLds {
@@ -80,196 +85,280 @@ __device__ __forceinline__ uint32_t ub_close(UBits &b) // returns total bits; fl
     return total;
 }
 
-__device__ __forceinline__ uint32_t fse_weights_wave0(EntropyLds &S, HufScratch *sc, int n_in)
+// The whole workgroup calls this.  Wave 0 builds the tables (uniform, scalar); the two interleaved state
+// chains (even / odd weight positions, walked from the last weight to the first) are inherently sequential, so
+// they are cut into chunks and every chunk is simulated for EVERY possible start state in parallel
+// (2 chains x 4 chunks x 32 states = 256 lanes, or 2 x 2 x 64); the true start states are then chained through
+// the end-state maps and 8 (4) lanes replay their chunk recording the emitted bits; assembly is parallel again.
+__device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc, int n_in, unsigned long long *stamps = nullptr)
 {
+#define FSE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
     const int n = __builtin_amdgcn_readfirstlane(n_in);
-    const int lane = (int)lane_id();
-    int wv[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { int idx = lane + 64 * j; wv[j] = idx < n ? (int)S.w[idx] : 255; }
-    int cnt[13];
-#pragma unroll
-    for (int v = 0; v < 13; v++) {
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) c += (int)__popcll(__ballot(wv[j] == v));
-        cnt[v] = c;
-    }
-    int maxw = 0, maxc = 0, present = 0, largest = 0;
-#pragma unroll
-    for (int v = 0; v < 13; v++) { if (cnt[v]) { maxw = v; present++; } }
-#pragma unroll
-    for (int v = 0; v < 13; v++) { if (cnt[v] > maxc) { maxc = cnt[v]; largest = v; } } // first maximum = lowest symbol
-    if (n <= 2) return 0;
-    if (maxc == n) return 1;
-    if (maxc == 1) return 0;
-    int table_log = 6;
-    {
-        int max_bits_src = highbit32_d((uint32_t)(n - 1)) - 2;
-        int min_bits_src = highbit32_d((uint32_t)n) + 1;
-        int min_bits_sym = highbit32_d((uint32_t)maxw) + 2;
-        int min_bits = min_bits_src < min_bits_sym ? min_bits_src : min_bits_sym;
-        if (max_bits_src < table_log) table_log = max_bits_src;
-        if (min_bits > table_log) table_log = min_bits;
-        if (table_log < 5) table_log = 5;
-        if (table_log > 6) table_log = 6;
-    }
-    const int table_size = 1 << table_log;
-    int norm[13], cumul[14];
-    {
-        int R = table_size - present, given = 0;
-#pragma unroll
-        for (int v = 0; v < 13; v++) {
-            int e = cnt[v] ? (cnt[v] * R) / n : 0;
-            norm[v] = cnt[v] ? 1 + e : 0;
-            given += e;
-        }
-#pragma unroll
-        for (int v = 0; v < 13; v++) if (v == largest) norm[v] += R - given;
-        cumul[0] = 0;
-#pragma unroll
-        for (int v = 0; v < 13; v++) cumul[v + 1] = cumul[v] + norm[v];
-    }
-    // ---- FSE_writeNCount as a plain LSB-first bit stream (same bytes as the 16-bit-flush original)
+    const uint32_t t = threadIdx.x, wave = t >> 6;
+    const int lane = (int)(t & 63);
     UBits nc = {0ull, 0, 0, 0};
-    {
-        int remaining = table_size + 1, threshold = table_size, nb = table_log + 1, prev0 = 0, run = 0;
-        ub_put(nc, (uint32_t)(table_log - 5), 4);
+    uint32_t nc_bytes = 0;
+    // S.misc[22]: 0 = go on, else 1 + early result; [23] table_log
+    if (wave == 0) {
+        int wv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { int idx = lane + 64 * j; wv[j] = idx < n ? (int)S.w[idx] : 255; }
+        int cnt[13];
 #pragma unroll
         for (int v = 0; v < 13; v++) {
-            if (v <= maxw && remaining > 1) {
-                if (prev0 && norm[v] == 0) { run++; }
-                else {
-                    if (prev0) { // close the zero run: 2-bit repeat codes (run <= 11 here)
-                        if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
-                        if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
-                        if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
-                        ub_put(nc, (uint32_t)run, 2);
-                        run = 0;
-                    }
-                    int c = norm[v];
-                    int max = (2 * threshold - 1) - remaining;
-                    remaining -= c;
-                    c++;
-                    if (c >= threshold) c += max;
-                    ub_put(nc, (uint32_t)c, nb - (c < max ? 1 : 0));
-                    prev0 = (c == 1);
+            int c = 0;
 #pragma unroll
-                    for (int q = 0; q < 7; q++) if (remaining < threshold) { nb--; threshold >>= 1; }
+            for (int j = 0; j < 4; j++) c += (int)__popcll(__ballot(wv[j] == v));
+            cnt[v] = c;
+        }
+        int maxw = 0, maxc = 0, present = 0, largest = 0;
+#pragma unroll
+        for (int v = 0; v < 13; v++) { if (cnt[v]) { maxw = v; present++; } }
+#pragma unroll
+        for (int v = 0; v < 13; v++) { if (cnt[v] > maxc) { maxc = cnt[v]; largest = v; } } // first maximum = lowest symbol
+        int early = 0;
+        if (n <= 2) early = 1;            // result 0
+        else if (maxc == n) early = 2;    // result 1: single symbol
+        else if (maxc == 1) early = 1;    // result 0: not compressible
+        if (early) { if (lane == 0) S.misc[22] = (uint32_t)early; }
+        else {
+            int table_log = 6;
+            {
+                int max_bits_src = highbit32_d((uint32_t)(n - 1)) - 2;
+                int min_bits_src = highbit32_d((uint32_t)n) + 1;
+                int min_bits_sym = highbit32_d((uint32_t)maxw) + 2;
+                int min_bits = min_bits_src < min_bits_sym ? min_bits_src : min_bits_sym;
+                if (max_bits_src < table_log) table_log = max_bits_src;
+                if (min_bits > table_log) table_log = min_bits;
+                if (table_log < 5) table_log = 5;
+                if (table_log > 6) table_log = 6;
+            }
+            const int table_size = 1 << table_log;
+            int norm[13], cumul[14];
+            {
+                int R = table_size - present, given = 0;
+#pragma unroll
+                for (int v = 0; v < 13; v++) {
+                    int e = cnt[v] ? (cnt[v] * R) / n : 0;
+                    norm[v] = cnt[v] ? 1 + e : 0;
+                    given += e;
+                }
+#pragma unroll
+                for (int v = 0; v < 13; v++) if (v == largest) norm[v] += R - given;
+                cumul[0] = 0;
+#pragma unroll
+                for (int v = 0; v < 13; v++) cumul[v + 1] = cumul[v] + norm[v];
+            }
+            // ---- FSE_writeNCount as a plain LSB-first bit stream (same bytes as the 16-bit-flush original)
+            {
+                int remaining = table_size + 1, threshold = table_size, nb = table_log + 1, prev0 = 0, run = 0;
+                ub_put(nc, (uint32_t)(table_log - 5), 4);
+#pragma unroll
+                for (int v = 0; v < 13; v++) {
+                    if (v <= maxw && remaining > 1) {
+                        if (prev0 && norm[v] == 0) { run++; }
+                        else {
+                            if (prev0) { // close the zero run: 2-bit repeat codes (run <= 11 here)
+                                if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
+                                if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
+                                if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
+                                ub_put(nc, (uint32_t)run, 2);
+                                run = 0;
+                            }
+                            int c = norm[v];
+                            int max = (2 * threshold - 1) - remaining;
+                            remaining -= c;
+                            c++;
+                            if (c >= threshold) c += max;
+                            ub_put(nc, (uint32_t)c, nb - (c < max ? 1 : 0));
+                            prev0 = (c == 1);
+#pragma unroll
+                            for (int q = 0; q < 7; q++) if (remaining < threshold) { nb--; threshold >>= 1; }
+                        }
+                    }
                 }
             }
+            nc_bytes = (ub_close(nc) + 7) >> 3;
+            // ---- FSE_buildCTable: lane u owns table position u
+            const int mask = table_size - 1;
+            const int inv = table_size == 32 ? 7 : 3; // step^-1 mod table_size (step 23: 23*7 = 161; step 43: 43*3 = 129)
+            {
+                int my_sym = 0;
+                int k = (lane * inv) & mask; // spread order index of position `lane`: pos_k = (k*step) & mask
+#pragma unroll
+                for (int v = 0; v < 13; v++) if (k >= cumul[v] && k < cumul[v + 1]) my_sym = v;
+                int rank = 0, base = 0;
+#pragma unroll
+                for (int v = 0; v < 13; v++) {
+                    unsigned long long bm = __ballot(lane < table_size && my_sym == v);
+                    if (my_sym == v) { rank = (int)__popcll(bm & ((1ull << lane) - 1)); base = cumul[v]; }
+                }
+                if (lane < table_size) sc->state_table[base + rank] = (uint16_t)(table_size + lane);
+            }
+#pragma unroll
+            for (int v = 0; v < 13; v++) {
+                if (lane == v) {
+                    int nv = norm[v], dnb, dfs;
+                    if (nv == 0) { dnb = ((table_log + 1) << 16) - table_size; dfs = 0; }
+                    else if (nv == 1) { dnb = (table_log << 16) - table_size; dfs = cumul[v] - 1; }
+                    else {
+                        int mbo = table_log - highbit32_d((uint32_t)(nv - 1));
+                        dnb = (mbo << 16) - (nv << mbo);
+                        dfs = cumul[v] - nv;
+                    }
+                    sc->dnb[v] = dnb;
+                    sc->dfs[v] = dfs;
+                }
+            }
+            wave_lds_sync();
+            // FSE_initCState2 for the last two positions: no output
+            if (lane < 2) {
+                const int i = n - 1 - lane;
+                int sy = S.w[i], dnb = sc->dnb[sy], dfs = sc->dfs[sy];
+                uint32_t nb_out = (uint32_t)(dnb + (1 << 15)) >> 16;
+                uint32_t value = (nb_out << 16) - (uint32_t)dnb;
+                sc->start[i & 1][0] = sc->state_table[(value >> nb_out) + (uint32_t)dfs];
+            }
+            if (lane == 0) { S.misc[22] = 0; S.misc[23] = (uint32_t)table_log; }
         }
     }
-    const uint32_t nc_bytes = (ub_close(nc) + 7) >> 3;
-    // ---- FSE_buildCTable: lane u owns table position u
-    const int mask = table_size - 1;
-    const int inv = table_size == 32 ? 7 : 3; // step^-1 mod table_size (step 23: 23*7 = 161; step 43: 43*3 = 129)
+    __syncthreads();
+    FSE_STAMP(12);
+    if (S.misc[22]) return S.misc[22] - 1;
+    const int table_log = (int)S.misc[23], table_size = 1 << table_log;
+    const int top = n - 3;                      // highest position that emits bits
+    const int nq = 128 / table_size;            // chunks per chain: 4 (32 states) or 2 (64 states)
+    const int CH = 128 / nq;                    // steps per chunk
+    // chain c holds the positions of parity c, walked downwards: step k <-> position top_c - 2k
     {
-        int my_sym = 0;
-        int k = (lane * inv) & mask; // spread order index of position `lane`: pos_k = (k*step) & mask
-#pragma unroll
-        for (int v = 0; v < 13; v++) if (k >= cumul[v] && k < cumul[v + 1]) my_sym = v;
-        int rank = 0, base = 0;
-#pragma unroll
-        for (int v = 0; v < 13; v++) {
-            unsigned long long bm = __ballot(lane < table_size && my_sym == v);
-            if (my_sym == v) { rank = (int)__popcll(bm & ((1ull << lane) - 1)); base = cumul[v]; }
+        const int c = (int)(t >> 7), q = (int)((t & 127) / (uint32_t)table_size), u = (int)(t & (uint32_t)(table_size - 1));
+        const int top_c = ((top & 1) == c) ? top : top - 1;
+        uint32_t st = (uint32_t)(table_size + u);
+        int p = top_c - 2 * q * CH;
+        for (int k = 0; k < CH && p >= 0; k++, p -= 2) {
+            int sy = S.w[p];
+            uint32_t nb = (st + (uint32_t)sc->dnb[sy]) >> 16;
+            st = sc->state_table[(st >> nb) + (uint32_t)sc->dfs[sy]];
         }
-        if (lane < table_size) sc->state_table[base + rank] = (uint16_t)(table_size + lane);
+        sc->endmap[c][q][u] = (uint8_t)(st - (uint32_t)table_size);
     }
-    wave_lds_sync();
-    const int st_v = lane < table_size ? (int)sc->state_table[lane] : 0; // lane j holds stateTable[j]
-    int dnb_v = 0, dfs_v = 0;                                            // lane s holds the transform of symbol s
+    __syncthreads();
+    FSE_STAMP(13);
+    if (t < 2) { // chain the true start states through the end-state maps
+        uint32_t st = sc->start[t][0];
+        for (int q = 0; q < nq; q++) {
+            sc->start[t][q] = st;
+            st = (uint32_t)table_size + sc->endmap[t][q][st - (uint32_t)table_size];
+        }
+        sc->fin[t] = st;
+    }
+    sc->rec[t] = 0;
+    __syncthreads();
+    if ((t & (uint32_t)(table_size - 1)) == 0) { // one lane per chunk replays it from its true start state, recording the output
+        const int c = (int)(t >> 7), q = (int)((t & 127) / (uint32_t)table_size);
+        const int top_c = ((top & 1) == c) ? top : top - 1;
+        uint32_t st = sc->start[c][q];
+        int p = top_c - 2 * q * CH;
+        for (int k = 0; k < CH && p >= 0; k++, p -= 2) {
+            int sy = S.w[p];
+            uint32_t nb = (st + (uint32_t)sc->dnb[sy]) >> 16;
+            sc->rec[p] = (st & ((1u << nb) - 1)) | (nb << 16);
+            st = sc->state_table[(st >> nb) + (uint32_t)sc->dfs[sy]];
+        }
+    }
+    __syncthreads();
+    FSE_STAMP(14);
+    // ---- parallel assembly by wave 0: position p is emitted after every position > p (p <= top), so its bit
+    // offset is the number of bits of all higher positions
+    uint32_t result = 0;
+    if (wave == 0) {
+        sc->fse_bits[lane] = 0;
+        wave_lds_sync();
+        uint32_t above = 0; // bits of the registers j' > j
 #pragma unroll
-    for (int v = 0; v < 13; v++) {
-        if (lane == v) {
-            int nv = norm[v];
-            if (nv == 0) { dnb_v = ((table_log + 1) << 16) - table_size; dfs_v = 0; }
-            else if (nv == 1) { dnb_v = (table_log << 16) - table_size; dfs_v = cumul[v] - 1; }
-            else {
-                int mbo = table_log - highbit32_d((uint32_t)(nv - 1));
-                dnb_v = (mbo << 16) - (nv << mbo);
-                dfs_v = cumul[v] - nv;
+        for (int j = 3; j >= 0; j--) {
+            uint32_t r = sc->rec[64 * j + lane];
+            uint32_t nbj = r >> 16, bits = r & 0xFFFF;
+            uint32_t incl = wave_incl_scan(nbj);
+            uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t off = above + (tot - incl);
+            if (nbj) {
+                uint32_t w = off >> 5, sh = off & 31;
+                atomicOr(&sc->fse_bits[w], bits << sh);
+                if (sh + nbj > 32) atomicOr(&sc->fse_bits[w + 1], bits >> (32 - sh));
+            }
+            above += tot;
+        }
+        // tail: flush state2 (odd positions), then state1 (even), then the end mark
+        uint32_t total_bits = above;
+        if (lane == 0) {
+            unsigned long long tail = (unsigned long long)(sc->fin[1] & (uint32_t)(table_size - 1)) |
+                                      ((unsigned long long)(sc->fin[0] & (uint32_t)(table_size - 1)) << table_log) | (1ull << (2 * table_log));
+            uint32_t w = total_bits >> 5, sh = total_bits & 31;
+            atomicOr(&sc->fse_bits[w], (uint32_t)(tail << sh));
+            if (sh + 2 * table_log + 1 > 32) atomicOr(&sc->fse_bits[w + 1], (uint32_t)((tail << sh) >> 32));
+        }
+        total_bits += 2 * (uint32_t)table_log + 1;
+        const uint32_t fse_bytes = (total_bits + 7) >> 3;
+        // ---- NCount bytes, then the FSE stream, into the tree description
+        if (lane < 8) sc->nc_bits[lane] = (uint32_t)nc.v;
+        wave_lds_sync();
+        uint8_t *dst = sc->tree + 1;
+        const uint8_t *nb8 = (const uint8_t *)sc->nc_bits, *fb8 = (const uint8_t *)sc->fse_bits;
+        if ((uint32_t)lane < nc_bytes) dst[lane] = nb8[lane];
+        for (uint32_t i = (uint32_t)lane; i < fse_bytes; i += 64) dst[nc_bytes + i] = fb8[i];
+        result = nc_bytes + fse_bytes;
+    }
+    return result; // meaningful in wave 0
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chunk load + byte histogram.  src is 16-byte aligned global memory holding m bytes; the chunk lands in
+// S.chunk (zero padded) and the per-wave counts in lds_hist(S)[wave*256 + byte] (zeroed by the caller).
+// Skewed data (quality deltas are ~90 % zeros) would serialise LDS atomics on one bin, so every wave first
+// peels off its dominant byte: the candidate is the first byte the wave sees, matches are counted with
+// SWAR compares in registers and added once per wave; only the other bytes go through LDS atomics.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_chunk_and_histogram(EntropyLds &S, const uint8_t *src, const uint32_t m)
+{
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    uint32_t *hist = lds_hist(S) + wave * 256;
+    uint4 v[4];
+    uint32_t have[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { // all four loads in flight before the first use
+        uint32_t off = (t + 256 * q) * 16;
+        have[q] = off < m ? (m - off < 16 ? m - off : 16) : 0;
+        v[q] = make_uint4(0, 0, 0, 0);
+        if (have[q] == 16) v[q] = *(const uint4 *)(src + off);
+        else if (have[q]) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint32_t k = 0; k < have[q]; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
+            v[q] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v[0].x & 0xFF)); // wave-uniform candidate byte
+    const uint32_t cand4 = cand * 0x01010101u;
+    uint32_t n_cand = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        *(uint4 *)&S.chunk[(t + 256 * q) * 4] = v[q];
+        const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint32_t valid = have[q] >= 4u * d + 4 ? 0x80808080u : (have[q] > 4u * d ? (0x80808080u >> (8 * (4 * d + 4 - have[q]))) : 0u);
+            uint32_t eq = zero_bytes(w[d] ^ cand4) & valid;
+            n_cand += __popc(eq);
+            uint32_t other = valid & ~eq; // 0x80 per byte that still needs an atomic
+            while (other) {
+                int bit = __ffs(other) - 1; // 7, 15, 23 or 31
+                other &= other - 1;
+                atomicAdd(&hist[(w[d] >> (bit - 7)) & 0xFF], 1u);
             }
         }
     }
-    // per-position transforms, looked up in parallel (lane k, register j <-> position 64*j + k)
-    int dnbp[4], dfsp[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { dnbp[j] = __shfl(dnb_v, wv[j] & 15, WAVE); dfsp[j] = __shfl(dfs_v, wv[j] & 15, WAVE); }
-
-    // ---- the state chain, scalar: symbols from the last to the first, state1 = even, state2 = odd positions.
-    // The chain only advances the two states and records (bits, nbits) of every step in the lane that owns
-    // the position; the bit stream is assembled afterwards in parallel.
-    int rec[4] = {0, 0, 0, 0};  // bits | nbits << 16 of position 64*j + lane
-    uint32_t st0 = 0, st1 = 0;  // st0: even positions (CState1), st1: odd positions (CState2)
-    {
-        // FSE_initCState2 for the last two positions: no output
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int i = n - 1 - q, jj = i >> 6, l = i & 63;
-            int dnb = 0, dfs = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) if (jj == j) { dnb = __builtin_amdgcn_readlane(dnbp[j], l); dfs = __builtin_amdgcn_readlane(dfsp[j], l); }
-            uint32_t nb_out = (uint32_t)(dnb + (1 << 15)) >> 16;
-            uint32_t value = (nb_out << 16) - (uint32_t)dnb;
-            uint32_t ns = (uint32_t)__builtin_amdgcn_readlane(st_v, (int)((value >> nb_out) + (uint32_t)dfs));
-            if (i & 1) st1 = ns; else st0 = ns;
-        }
-    }
-    const int top = n - 3; // highest position that emits bits
-#pragma unroll
-    for (int j = 3; j >= 0; j--) {
-        int hi = top - 64 * j;
-        if (hi > 63) hi = 63;
-        for (int l = hi; l >= 0; l--) { // uniform trip count: scalar loop; 64*j is even, so parity(position) = parity(l)
-            int dnb = __builtin_amdgcn_readlane(dnbp[j], l);
-            int dfs = __builtin_amdgcn_readlane(dfsp[j], l);
-            uint32_t st = (l & 1) ? st1 : st0;
-            uint32_t nb_out = (st + (uint32_t)dnb) >> 16;
-            uint32_t bits = st & ((1u << nb_out) - 1);
-            uint32_t ns = (uint32_t)__builtin_amdgcn_readlane(st_v, (int)((st >> nb_out) + (uint32_t)dfs));
-            rec[j] = (lane == l) ? (int)(bits | (nb_out << 16)) : rec[j];
-            if (l & 1) st1 = ns; else st0 = ns;
-        }
-    }
-    // ---- parallel assembly: position p is emitted after every position > p (p <= top), so its bit offset is
-    // the number of bits of all higher positions
-    sc->fse_bits[lane] = 0;
-    wave_lds_sync();
-    uint32_t above = 0; // bits of the registers j' > j
-#pragma unroll
-    for (int j = 3; j >= 0; j--) {
-        uint32_t nbj = (uint32_t)rec[j] >> 16, bits = (uint32_t)rec[j] & 0xFFFF;
-        uint32_t incl = wave_incl_scan(nbj);
-        uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        uint32_t off = above + (tot - incl);
-        if (nbj) {
-            uint32_t w = off >> 5, sh = off & 31;
-            atomicOr(&sc->fse_bits[w], bits << sh);
-            if (sh + nbj > 32) atomicOr(&sc->fse_bits[w + 1], bits >> (32 - sh));
-        }
-        above += tot;
-    }
-    // tail: flush state2, then state1, then the end mark
-    uint32_t total_bits = above;
-    if (lane == 0) {
-        unsigned long long tail = (unsigned long long)(st1 & (uint32_t)(table_size - 1)) |
-                                  ((unsigned long long)(st0 & (uint32_t)(table_size - 1)) << table_log) | (1ull << (2 * table_log));
-        uint32_t w = total_bits >> 5, sh = total_bits & 31;
-        atomicOr(&sc->fse_bits[w], (uint32_t)(tail << sh));
-        if (sh + 2 * table_log + 1 > 32) atomicOr(&sc->fse_bits[w + 1], (uint32_t)((tail << sh) >> 32));
-    }
-    total_bits += 2 * (uint32_t)table_log + 1;
-    const uint32_t fse_bytes = (total_bits + 7) >> 3;
-    // ---- NCount bytes, then the FSE stream, into the tree description
-    if (lane < 8) sc->nc_bits[lane] = (uint32_t)nc.v;
-    wave_lds_sync();
-    uint8_t *dst = sc->tree + 1;
-    const uint8_t *nb8 = (const uint8_t *)sc->nc_bits, *fb8 = (const uint8_t *)sc->fse_bits;
-    if ((uint32_t)lane < nc_bytes) dst[lane] = nb8[lane];
-    for (uint32_t i = (uint32_t)lane; i < fse_bytes; i += 64) dst[nc_bytes + i] = fb8[i];
-    return nc_bytes + fse_bytes;
+    n_cand = wave_sum(n_cand);
+    if (lane == 0 && n_cand) atomicAdd(&hist[cand], n_cand);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -312,18 +401,21 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint32_t m, const uint
     uint32_t tree_size = 0, max_bits = 0;
     DBG_STOP(2);
     if (mode == 2) {
-        // ---- rank sort of the 256 keys (ascending; distinct when non-zero, ties among zeros by index)
+        // ---- sort the active symbols by (count, symbol): compact the non-zero keys, then every active key
+        //      counts the smaller ones (keys are distinct)
         {
-            uint32_t my = S.keys[t], rank = 0;
-#pragma unroll 16
-            for (uint32_t j = 0; j < 256; j += 4) {
-                uint4 k4 = *(const uint4 *)&S.keys[j];
-                rank += (k4.x < my) || (k4.x == my && j + 0 < t);
-                rank += (k4.y < my) || (k4.y == my && j + 1 < t);
-                rank += (k4.z < my) || (k4.z == my && j + 2 < t);
-                rank += (k4.w < my) || (k4.w == my && j + 3 < t);
-            }
-            S.sorted[rank] = my;
+            uint32_t my = S.keys[t];
+            unsigned long long bm = __ballot(my != 0);
+            if (lane == 0) S.misc[16 + wave] = (uint32_t)__popcll(bm);
+            __syncthreads();
+            uint32_t base = 0;
+            for (uint32_t w2 = 0; w2 < wave; w2++) base += S.misc[16 + w2];
+            if (my) S.sorted[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1))] = my; // compacted, unsorted
+            __syncthreads();
+            uint32_t mine = t < n_active ? S.sorted[t] : 0, rank = 0;
+            for (uint32_t j = 0; j < n_active; j++) rank += S.sorted[j] < mine;
+            __syncthreads();
+            if (t < n_active) S.sorted[256 - n_active + rank] = mine;
         }
         __syncthreads();
         DBG_STOP(3);
@@ -418,13 +510,11 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint32_t m, const uint
             if (2 * t < nw) sc->tree[1 + t] = (uint8_t)((S.w[2 * t] << 4) + S.w[2 * t + 1]);
             tree_size = (nw + 1) / 2 + 1;
         } else {
-            if (wave == 0) {
-                uint32_t h = fse_weights_wave0(S, sc, (int)nw);
-                if (lane == 0) {
-                    uint32_t ts = 0;
-                    if (h > 1 && h < nw / 2) { sc->tree[0] = (uint8_t)h; ts = h + 1; }
-                    S.misc[6] = ts;
-                }
+            uint32_t h = fse_weights_wg(S, sc, (int)nw, stamps); // all four waves; the size is valid in wave 0
+            if (t == 0) {
+                uint32_t ts = 0;
+                if (h > 1 && h < nw / 2) { sc->tree[0] = (uint8_t)h; ts = h + 1; }
+                S.misc[6] = ts;
             }
             __syncthreads();
             tree_size = S.misc[6];

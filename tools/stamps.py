@@ -19,8 +19,8 @@ buf = np.zeros((nch, 16), dtype=np.uint64)
 got = C.c_size_t(0)
 check(lib().fqz_debug_get_stamps(ctx.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), nch, C.byref(got)))
 names = ["seq", "qual", "hdr", "plus", "npos", "len"]
-order = [0, 1, 2, 3, 4, 10, 11, 5, 6, 7, 8, 9]
-labels = ["start", "load+hist", "classify", "ranksort", "huff+depth", "nbits", "weights", "tree(FSE/direct)", "codes+clear", "pass1", "hdr+pass2", "copyout"]
+order = [0, 1, 2, 3, 4, 10, 11, 12, 13, 14, 5, 6, 7, 8, 9]
+labels = ["start", "load+hist", "classify", "ranksort", "huff+depth", "nbits", "weights", "fse:tables", "fse:simulate", "fse:resolve+replay", "tree(FSE/direct)", "codes+clear", "pass1", "hdr+pass2", "copyout"]
 for s in range(6):
     sel = buf[buf[:, 15] == s]
     if not len(sel):
@@ -38,5 +38,5 @@ for s in range(6):
         d = np.where(ok, cur - prev, 0)
         parts.append("%s=%.0f" % (lab, d[ok].mean()))
         prev = np.where(ok, cur, prev)
-    tot = (src[:, [1,2,3,4,5,6,7,8,9,10,11]].max(axis=1).astype(np.int64) - src[:, 0].astype(np.int64)).mean()
+    tot = (src[:, [1,2,3,4,5,6,7,8,9,10,11,12,13,14]].max(axis=1).astype(np.int64) - src[:, 0].astype(np.int64)).mean()
     print("total=%.0f cyc | " % tot + " ".join(parts))
