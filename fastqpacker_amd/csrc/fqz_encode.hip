@@ -514,30 +514,51 @@ __global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const Bloc
 __device__ __forceinline__ void put_le32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 
 // csize has been scanned in place (exclusive prefix, total at [n_chunks])
-__global__ void k_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap)
+// one 256-thread workgroup, one thread per block: a block starts at
+//   36*b + 10*(non-empty frames before b) + (compressed chunk bytes before b)
+__global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    uint32_t n_blocks = info->n_blocks;
-    unsigned long long pos = 0;
-    for (uint32_t b = 0; b < n_blocks; b++) {
-        BlockPlan *p = &plans[b];
-        unsigned long long start = pos;
-        pos += 36;
-        for (int s = 0; s < FQZ_NS; s++) {
-            uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
-            uint32_t flen = nch ? 10 + (cpre[p->chunk_base[s] + nch] - cpre[p->chunk_base[s]]) : 0;
-            p->frame_off[s] = (uint32_t)pos;
-            p->frame_len[s] = flen;
-            pos += flen;
-            info->stream_comp[s] += flen;
+    __shared__ uint32_t sh[4];
+    __shared__ unsigned long long s_total;
+    if (blockIdx.x) return;
+    const uint32_t n_blocks = info->n_blocks, t = threadIdx.x;
+    uint32_t carry = 0; // non-empty frames in the blocks of earlier strips
+    unsigned long long comp[FQZ_NS] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t base = 0; base < n_blocks; base += 256) {
+        const uint32_t b = base + t;
+        BlockPlan *p = b < n_blocks ? &plans[b] : nullptr;
+        uint32_t nonempty = 0;
+        if (p) for (int s = 0; s < FQZ_NS; s++) nonempty += p->len[s] != 0;
+        uint32_t tot;
+        uint32_t before = carry + block_excl_scan_256(nonempty, sh, &tot);
+        carry += tot;
+        if (p) {
+            unsigned long long start = 36ull * b + 10ull * before + cpre[p->chunk_base[0]];
+            unsigned long long pos = start + 36;
+            for (int s = 0; s < FQZ_NS; s++) {
+                uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
+                uint32_t flen = nch ? 10 + (cpre[p->chunk_base[s] + nch] - cpre[p->chunk_base[s]]) : 0;
+                p->frame_off[s] = (uint32_t)pos;
+                p->frame_len[s] = flen;
+                pos += flen;
+                comp[s] += flen;
+            }
+            p->out_off = (uint32_t)start;
+            p->out_len = (uint32_t)(pos - start);
+            if (b + 1 == n_blocks) s_total = pos;
         }
-        p->out_off = (uint32_t)start;
-        p->out_len = (uint32_t)(pos - start);
+        __syncthreads();
     }
-    info->out_len = pos;
-    if (pos > out_cap || pos > 0xFFFFFFF0ull) { if (!info->status) info->status = FQZ_E_DST_SMALL; return; }
-    if (info->status) return;
-    for (uint32_t b = 0; b < n_blocks; b++) {
+    for (int s = 0; s < FQZ_NS; s++) if (comp[s]) atomicAdd(&info->stream_comp[s], comp[s]);
+    if (!n_blocks && t == 0) s_total = 0;
+    __syncthreads();
+    const unsigned long long total = s_total;
+    if (t == 0) {
+        info->out_len = total;
+        if ((total > out_cap || total > 0xFFFFFFF0ull) && !info->status) info->status = FQZ_E_DST_SMALL;
+    }
+    if (total > out_cap || total > 0xFFFFFFF0ull || info->status) return;
+    for (uint32_t b = t; b < n_blocks; b += 256) {
         BlockPlan *p = &plans[b];
         uint8_t *h = out + p->out_off;
         // BlockHeader v2: NumRecords, Seq, Qual, Header, Plus, NPositions, SeqLengths, OriginalSeq, OriginalQual
@@ -713,7 +734,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, st, "k_split_rest", hipLaunchKernelGGL(k_split_rest, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena, npos));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, 1, e.chunk_cap + 1, partials, pmax);
-    PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_out, out_cap));
+    PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));

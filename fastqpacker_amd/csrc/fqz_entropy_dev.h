@@ -23,6 +23,7 @@ struct HufScratch {          // aliases the (not yet used) output staging buffer
     uint32_t fse_bits[64];   // FSE bitstream of the weights (dword aligned)
     uint32_t nc_bits[8];     // FSE NCount header bits
     int dnb[16], dfs[16];    // FSE symbol transforms (deltaNbBits, deltaFindState)
+    int norm[16], cumul[16]; // normalised weight counts and their exclusive prefix
     uint32_t start[2][4];    // true start state of every chunk of the two state chains
     uint32_t fin[2];         // final states (flushed at the end of the stream)
     uint32_t rec[256];       // bits | nbits << 16 emitted at each weight position
@@ -43,6 +44,8 @@ struct EntropyLds {
 // per-wave histograms alias out[] beyond the HufScratch area; dead before out[] is cleared
 #define HIST_WORD_OFF 2048
 __device__ __forceinline__ uint32_t *lds_hist(EntropyLds &S) { return S.out + HIST_WORD_OFF; }
+// FSE state trace [chain 2][chunk 4][step 32][start state 32] (8 KiB) reuses the histogram area once that is dead
+__device__ __forceinline__ uint8_t *lds_trace(EntropyLds &S) { return (uint8_t *)(S.out + HIST_WORD_OFF); }
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -96,9 +99,7 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
     const int n = __builtin_amdgcn_readfirstlane(n_in);
     const uint32_t t = threadIdx.x, wave = t >> 6;
     const int lane = (int)(t & 63);
-    UBits nc = {0ull, 0, 0, 0};
-    uint32_t nc_bytes = 0;
-    // S.misc[22]: 0 = go on, else 1 + early result; [23] table_log
+    // S.misc[22]: 0 = go on, else 1 + early result; [23] table_log; [24] NCount bytes
     if (wave == 0) {
         int wv[4];
 #pragma unroll
@@ -134,81 +135,74 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
                 if (table_log > 6) table_log = 6;
             }
             const int table_size = 1 << table_log;
-            int norm[13], cumul[14];
-            {
-                int R = table_size - present, given = 0;
+            // lane v owns weight symbol v: normalised count and its exclusive prefix
+            int my_cnt = 0;
 #pragma unroll
-                for (int v = 0; v < 13; v++) {
-                    int e = cnt[v] ? (cnt[v] * R) / n : 0;
-                    norm[v] = cnt[v] ? 1 + e : 0;
-                    given += e;
-                }
-#pragma unroll
-                for (int v = 0; v < 13; v++) if (v == largest) norm[v] += R - given;
-                cumul[0] = 0;
-#pragma unroll
-                for (int v = 0; v < 13; v++) cumul[v + 1] = cumul[v] + norm[v];
-            }
-            // ---- FSE_writeNCount as a plain LSB-first bit stream (same bytes as the 16-bit-flush original)
-            {
+            for (int v = 0; v < 13; v++) if (lane == v) my_cnt = cnt[v];
+            const int R = table_size - present;
+            int e = my_cnt ? (my_cnt * R) / n : 0;
+            int my_norm = my_cnt ? 1 + e : 0;
+            int given = (int)wave_sum((uint32_t)e);
+            if (lane == largest) my_norm += R - given;
+            int my_cumul = (int)wave_incl_scan((uint32_t)my_norm) - my_norm;
+            if (lane < 16) { sc->norm[lane] = my_norm; sc->cumul[lane] = my_cumul; }
+            wave_lds_sync();
+            // ---- FSE_writeNCount as a plain LSB-first bit stream (same bytes as the 16-bit-flush original); one lane
+            if (lane == 0) {
+                uint8_t *ncb = (uint8_t *)sc->nc_bits;
+                unsigned long long acc = 0;
+                int nbacc = 0;
+                uint32_t outp = 0;
                 int remaining = table_size + 1, threshold = table_size, nb = table_log + 1, prev0 = 0, run = 0;
-                ub_put(nc, (uint32_t)(table_log - 5), 4);
-#pragma unroll
-                for (int v = 0; v < 13; v++) {
-                    if (v <= maxw && remaining > 1) {
-                        if (prev0 && norm[v] == 0) { run++; }
-                        else {
-                            if (prev0) { // close the zero run: 2-bit repeat codes (run <= 11 here)
-                                if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
-                                if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
-                                if (run >= 3) { ub_put(nc, 3u, 2); run -= 3; }
-                                ub_put(nc, (uint32_t)run, 2);
-                                run = 0;
-                            }
-                            int c = norm[v];
-                            int max = (2 * threshold - 1) - remaining;
-                            remaining -= c;
-                            c++;
-                            if (c >= threshold) c += max;
-                            ub_put(nc, (uint32_t)c, nb - (c < max ? 1 : 0));
-                            prev0 = (c == 1);
-#pragma unroll
-                            for (int q = 0; q < 7; q++) if (remaining < threshold) { nb--; threshold >>= 1; }
-                        }
+                acc = (unsigned long long)(table_log - 5); nbacc = 4;
+                for (int v = 0; v <= maxw && remaining > 1; v++) {
+                    int nv = sc->norm[v];
+                    if (prev0 && nv == 0) { run++; continue; }
+                    if (prev0) { // close the zero run: 2-bit repeat codes
+                        while (run >= 3) { acc |= 3ull << nbacc; nbacc += 2; run -= 3; }
+                        acc |= (unsigned long long)run << nbacc; nbacc += 2;
+                        run = 0;
                     }
+                    int c = nv;
+                    int max = (2 * threshold - 1) - remaining;
+                    remaining -= c;
+                    c++;
+                    if (c >= threshold) c += max;
+                    acc |= (unsigned long long)c << nbacc;
+                    nbacc += nb - (c < max ? 1 : 0);
+                    prev0 = (c == 1);
+                    while (remaining < threshold) { nb--; threshold >>= 1; }
+                    while (nbacc >= 8) { ncb[outp++] = (uint8_t)acc; acc >>= 8; nbacc -= 8; }
                 }
+                while (nbacc > 0) { ncb[outp++] = (uint8_t)acc; acc >>= 8; nbacc -= 8; }
+                S.misc[24] = outp;
             }
-            nc_bytes = (ub_close(nc) + 7) >> 3;
             // ---- FSE_buildCTable: lane u owns table position u
             const int mask = table_size - 1;
             const int inv = table_size == 32 ? 7 : 3; // step^-1 mod table_size (step 23: 23*7 = 161; step 43: 43*3 = 129)
             {
-                int my_sym = 0;
                 int k = (lane * inv) & mask; // spread order index of position `lane`: pos_k = (k*step) & mask
-#pragma unroll
-                for (int v = 0; v < 13; v++) if (k >= cumul[v] && k < cumul[v + 1]) my_sym = v;
-                int rank = 0, base = 0;
+                int my_sym = 0;              // = number of symbols whose range ends at or before k
+                for (int v = 0; v < 12; v++) my_sym += (sc->cumul[v + 1] <= k && v + 1 <= maxw) ? 1 : 0;
+                int rank = 0;
 #pragma unroll
                 for (int v = 0; v < 13; v++) {
                     unsigned long long bm = __ballot(lane < table_size && my_sym == v);
-                    if (my_sym == v) { rank = (int)__popcll(bm & ((1ull << lane) - 1)); base = cumul[v]; }
+                    if (my_sym == v) rank = (int)__popcll(bm & ((1ull << lane) - 1));
                 }
-                if (lane < table_size) sc->state_table[base + rank] = (uint16_t)(table_size + lane);
+                if (lane < table_size) sc->state_table[sc->cumul[my_sym] + rank] = (uint16_t)(table_size + lane);
             }
-#pragma unroll
-            for (int v = 0; v < 13; v++) {
-                if (lane == v) {
-                    int nv = norm[v], dnb, dfs;
-                    if (nv == 0) { dnb = ((table_log + 1) << 16) - table_size; dfs = 0; }
-                    else if (nv == 1) { dnb = (table_log << 16) - table_size; dfs = cumul[v] - 1; }
-                    else {
-                        int mbo = table_log - highbit32_d((uint32_t)(nv - 1));
-                        dnb = (mbo << 16) - (nv << mbo);
-                        dfs = cumul[v] - nv;
-                    }
-                    sc->dnb[v] = dnb;
-                    sc->dfs[v] = dfs;
+            if (lane < 13) {
+                int nv = my_norm, dnb, dfs;
+                if (nv == 0) { dnb = ((table_log + 1) << 16) - table_size; dfs = 0; }
+                else if (nv == 1) { dnb = (table_log << 16) - table_size; dfs = my_cumul - 1; }
+                else {
+                    int mbo = table_log - highbit32_d((uint32_t)(nv - 1));
+                    dnb = (mbo << 16) - (nv << mbo);
+                    dfs = my_cumul - nv;
                 }
+                sc->dnb[lane] = dnb;
+                sc->dfs[lane] = dfs;
             }
             wave_lds_sync();
             // FSE_initCState2 for the last two positions: no output
@@ -229,16 +223,21 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
     const int top = n - 3;                      // highest position that emits bits
     const int nq = 128 / table_size;            // chunks per chain: 4 (32 states) or 2 (64 states)
     const int CH = 128 / nq;                    // steps per chunk
-    // chain c holds the positions of parity c, walked downwards: step k <-> position top_c - 2k
+    // chain c holds the positions of parity c, walked downwards: step k <-> position top_c - 2k.
+    // trace[c][q][k][u] = state after step k of chunk q when the chunk is entered in state u (table_size == 32 only)
+    uint8_t *trace = lds_trace(S);
+    const bool traced = table_size == 32;
     {
         const int c = (int)(t >> 7), q = (int)((t & 127) / (uint32_t)table_size), u = (int)(t & (uint32_t)(table_size - 1));
         const int top_c = ((top & 1) == c) ? top : top - 1;
         uint32_t st = (uint32_t)(table_size + u);
         int p = top_c - 2 * q * CH;
+        uint8_t *tr = trace + ((c * 4 + q) * 32) * 32 + u;
         for (int k = 0; k < CH && p >= 0; k++, p -= 2) {
             int sy = S.w[p];
             uint32_t nb = (st + (uint32_t)sc->dnb[sy]) >> 16;
             st = sc->state_table[(st >> nb) + (uint32_t)sc->dfs[sy]];
+            if (traced) tr[k * 32] = (uint8_t)st;
         }
         sc->endmap[c][q][u] = (uint8_t)(st - (uint32_t)table_size);
     }
@@ -254,7 +253,19 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
     }
     sc->rec[t] = 0;
     __syncthreads();
-    if ((t & (uint32_t)(table_size - 1)) == 0) { // one lane per chunk replays it from its true start state, recording the output
+    if (traced) {
+        // every weight position looks up the state it is encoded from and derives its output bits
+        const int p = (int)t;
+        if (p <= top) {
+            const int c = p & 1, top_c = ((top & 1) == c) ? top : top - 1;
+            const int kg = (top_c - p) >> 1, q = kg / CH, k = kg - q * CH;
+            const uint32_t s0 = sc->start[c][q];
+            const uint32_t st = k ? (uint32_t)trace[(((c * 4 + q) * 32) + (k - 1)) * 32 + (int)(s0 - 32u)] : s0;
+            const int sy = S.w[p];
+            const uint32_t nb = (st + (uint32_t)sc->dnb[sy]) >> 16;
+            sc->rec[p] = (st & ((1u << nb) - 1)) | (nb << 16);
+        }
+    } else if ((t & (uint32_t)(table_size - 1)) == 0) { // 64-state tables: one lane per chunk replays it from its true start state
         const int c = (int)(t >> 7), q = (int)((t & 127) / (uint32_t)table_size);
         const int top_c = ((top & 1) == c) ? top : top - 1;
         uint32_t st = sc->start[c][q];
@@ -301,7 +312,7 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
         total_bits += 2 * (uint32_t)table_log + 1;
         const uint32_t fse_bytes = (total_bits + 7) >> 3;
         // ---- NCount bytes, then the FSE stream, into the tree description
-        if (lane < 8) sc->nc_bits[lane] = (uint32_t)nc.v;
+        const uint32_t nc_bytes = S.misc[24];
         wave_lds_sync();
         uint8_t *dst = sc->tree + 1;
         const uint8_t *nb8 = (const uint8_t *)sc->nc_bits, *fb8 = (const uint8_t *)sc->fse_bits;
