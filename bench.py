@@ -155,6 +155,7 @@ def main():
     fqz_dev = d_out[:out_bytes].clone()
     d_back = torch.empty(in_bytes + 4096, dtype=torch.uint8, device=dev)
     dres = BatchResult()
+    dkern = {}
 
     def decode_step():
         fq._lib.check(lib().fqz_decode_batch_dev(ctx.handle, fqz_dev.data_ptr(), out_bytes, 2, fq.ENCODING_PHRED33, d_back.data_ptr(),
@@ -163,13 +164,17 @@ def main():
         decode_step()
         roundtrip_ok = bool(dres.out_len == in_bytes and torch.equal(d_back[:in_bytes], d_text))
         torch.cuda.synchronize()
+        if a.profile:
+            ctx.profile(True)
         t1 = time.perf_counter()
         for _ in range(a.decode_steps):
             decode_step()
         torch.cuda.synchronize()
         ddt = (time.perf_counter() - t1) / max(1, a.decode_steps)
+        dkern = ctx.profile_read() if a.profile else {}
+        ctx.profile(False)
     except fq.FqzError as e:  # only reachable in the FQZ_DBG_STOP timing experiments (garbage blocks)
-        roundtrip_ok, ddt = False, float("inf")
+        roundtrip_ok, ddt, dkern = False, float("inf"), {}
         print("decode failed: %s" % e, file=sys.stderr)
 
     if rank != 0:
@@ -210,6 +215,7 @@ def main():
         "decode_MBps": round(in_bytes / ddt / 1e6, 1), "roundtrip_bit_exact": roundtrip_ok,
         "input_frac_of_hbm_peak": round(total_in / dt * a.steps / 1e9 / (HBM_PEAK_GBS * world), 4),
         "roofline": roof, "kernel_ms": kernels,
+        "decode_kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in dkern.items()},
         "stream_ratio": {n: (round(res.stream_raw[i] / res.stream_comp[i], 3) if res.stream_comp[i] else None)
                          for i, n in enumerate(fq.STREAM_NAMES)},
     }

@@ -140,3 +140,35 @@ def test_encoder_primitives_match_reference_tables(fq):
     q = bytes(rng.integers(33, 74, 5000, dtype=np.uint8))
     assert bytes(E.DeltaDecode(E.DeltaEncode(bytearray(q)))) == q
     assert bytes(E.DeltaEncode(bytearray(q))) == O.delta_encode(q)
+
+
+def test_walk_edge_cases_long_headers_and_records_spanning_tiles(fq):
+    """The decoder cuts the length-prefixed streams into 16 KiB tiles: cover entries beyond the precomputed
+    range (headers > 254 bytes), records longer than a tile (40 kbp of N -> an 80 KB nPos record) and many
+    tiny records."""
+    rng = np.random.default_rng(77)
+    recs = []
+    for i in range(400):
+        hlen = int(rng.choice([5, 40, 250, 255, 256, 300, 1000, 5000]))
+        hdr = bytes(rng.integers(97, 123, hlen, dtype=np.uint8))
+        L = int(rng.choice([0, 1, 7, 150, 400]))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), L))
+        plus = hdr[: int(rng.integers(0, 3)) * 100]
+        q = bytes(rng.integers(33, 74, L, dtype=np.uint8))
+        recs.append(b"@" + hdr + b"\n" + seq + b"\n+" + plus + b"\n" + q + b"\n")
+    big = b"N" * 40000 + b"ACGT" * 100
+    recs.insert(200, b"@big\n" + big + b"\n+\n" + b"I" * len(big) + b"\n")
+    recs.insert(201, b"@big2\n" + big[::-1] + b"\n+\n" + b"#" * len(big) + b"\n")
+    text = b"".join(recs)
+    z = O.compress(text, batch_records=150)
+    assert fq.compress.Decompress(z) == text
+    z2 = fq.compress.Compress(text)
+    assert z2 == O.compress(text)
+    assert fq.compress.Decompress(z2) == text
+    # truncated streams are refused with the reference's messages
+    blk, n = fq.compress.encode_block(text, 0)
+    hdr = [int.from_bytes(blk[4 * i: 4 * i + 4], "little") for i in range(9)]
+    bad = bytearray(blk)
+    bad[0:4] = (hdr[0] + 5).to_bytes(4, "little")    # claims more records than the streams hold
+    with pytest.raises(fq.FqzError, match="truncated"):
+        fq.compress.decode_block(bytes(bad), 2, 0)
