@@ -77,6 +77,7 @@ SIGNATURES = {
     "fqz_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "fqz_ctx_destroy": (None, [_vp]),
     "fqz_device_count": (C.c_int, []),
+    "fqz_ctx_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "fqz_write_file_header": (None, [C.POINTER(FileHeader), _u8p]),
     "fqz_read_file_header": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(FileHeader)]),
     "fqz_write_block_header": (C.c_int, [C.POINTER(BlockHeader), C.c_uint8, _u8p]),
@@ -182,6 +183,12 @@ def _ctx_profile_read(self):
     return {k: (ms[i], calls[i]) for i, k in enumerate(keys)}
 
 
+def _ctx_fused_split(self, on=True):
+    """FQZ_OPT_FUSED_SPLIT: build entropy chunks in LDS straight from the text (no pre-entropy streams in HBM)."""
+    check(lib().fqz_ctx_set_option(self._h, 1, 1 if on else 0))
+
+
+Ctx.fused_split = _ctx_fused_split
 Ctx.profile = _ctx_profile
 Ctx.profile_read = _ctx_profile_read
 

@@ -70,6 +70,7 @@ struct EncState {
     DevBuf info;      // EncInfo
     DevBuf tile_cnt;  // u32[n_tiles+1]
     DevBuf ls;        // u32[line_cap+1] line starts
+    DevBuf lf;        // u8[line_cap+1] line flags: '\r' before the newline | first-byte class << 1
     DevBuf E;         // u32[5][rec_cap+1]: seq, qual, hdr, plus, npos sizes -> exclusive offsets
     DevBuf plans;     // BlockPlan[block_cap]
     DevBuf arena;     // seq/qual/hdr/plus/len pre-entropy streams
@@ -78,6 +79,9 @@ struct EncState {
     DevBuf csize;     // u32[chunk_cap+1] -> exclusive prefix
     DevBuf partials;  // scan partial sums
     DevBuf stamps;    // diagnostic s_memtime stamps (FQZ_DBG_STAMPS)
+    DevBuf chunk_rec; // first record of every main chunk (fused pipeline)
+    bool unfused = true;        // materialise the six pre-entropy streams in HBM (default; the fused variant is FQZ_OPT_FUSED_SPLIT)
+    bool streams_valid = false; // the last encode ran unfused: fqz_debug_get_streams can read them
     PinnedBuf h_info; // EncInfo
     PinnedBuf h_plans;
 };

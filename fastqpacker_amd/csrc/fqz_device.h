@@ -54,6 +54,13 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
     return v;
 }
 __device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t *p)
+{
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void store_u128_unaligned(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {

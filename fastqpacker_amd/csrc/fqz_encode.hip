@@ -131,29 +131,45 @@ __global__ __launch_bounds__(256) void k_count_nl(const uint8_t *text, uint32_t 
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(256) void k_line_starts(const uint8_t *text, uint32_t n, const uint32_t *tile_off, uint32_t *ls,
+// Line index + line flags.  Newline j (1-based) ends line j-1 and starts line j:
+//   ls[j] = text offset of line j;  lf[j] = (byte before the newline is '\r') | class of line j's first byte << 1
+// (class 1 = '@', 2 = '+', 0 = anything else / no byte).  With them the record table never touches the text again.
+__global__ __launch_bounds__(256) void k_line_starts(const uint8_t *text, uint32_t n, const uint32_t *tile_off, uint32_t *ls, uint8_t *lf,
                                                      uint32_t line_cap)
 {
     __shared__ uint32_t sh[4];
-    uint32_t off = blockIdx.x * FQZ_TILE + threadIdx.x * 16;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[16 + FQZ_TILE + 16]; // the tile's text with one neighbour byte either side
+    const uint32_t t = threadIdx.x;
+    uint32_t off = blockIdx.x * FQZ_TILE + t * 16;
     uint4 v = load_text16(text, off, n);
+    *(uint4 *)&tile[16 + 16 * t] = v;
+    if (t == 0) tile[15] = off ? text[off - 1] : 0;
+    if (t == 255) tile[16 + FQZ_TILE] = off + 16 < n ? text[off + 16] : 0;
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
     uint32_t m[4], c = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { m[k] = zero_bytes(w[k] ^ 0x0A0A0A0Au); c += __popc(m[k]); }
     uint32_t tot;
-    uint32_t idx = tile_off[blockIdx.x] + block_excl_scan_256(c, sh, &tot);
-    if (blockIdx.x == 0 && threadIdx.x == 0) ls[0] = 0;
+    uint32_t idx = tile_off[blockIdx.x] + block_excl_scan_256(c, sh, &tot); // (its barriers also publish tile[])
+    if (blockIdx.x == 0 && t == 0) {
+        ls[0] = 0;
+        lf[0] = (uint8_t)(n ? (((w[0] & 0xFF) == '@' ? 1 : (w[0] & 0xFF) == '+' ? 2 : 0) << 1) : 0);
+    }
     if (c) {
+        const uint8_t *mine = tile + 16 + 16 * t;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             uint32_t mk = m[k];
             while (mk) {
                 int bit = __ffs(mk) - 1; // 7, 15, 23, 31
                 mk &= mk - 1;
-                uint32_t pos = off + 4 * k + (bit >> 3);
+                const int q = 4 * k + (bit >> 3);
                 idx++;
-                if (idx <= line_cap) ls[idx] = pos + 1; // line idx starts after newline idx-1
+                if (idx <= line_cap) {
+                    const uint32_t before = mine[q - 1], after = mine[q + 1];
+                    ls[idx] = off + q + 1; // line idx starts after newline idx
+                    lf[idx] = (uint8_t)((before == '\r' ? 1 : 0) | (after == '@' ? 2 : after == '+' ? 4 : 0));
+                }
             }
         }
     }
@@ -189,8 +205,8 @@ __device__ __forceinline__ void line_span(const uint8_t *text, const uint32_t *l
     *len = l;
 }
 
-// one thread per record: validation + per-record stream sizes
-__global__ __launch_bounds__(256) void k_record_meta(const uint8_t *text, const uint32_t *ls, EncInfo *info, uint32_t *E, uint32_t estride,
+// one thread per record: validation + per-record stream sizes, from the line index and line flags alone
+__global__ __launch_bounds__(256) void k_record_meta(const uint32_t *ls, const uint8_t *lf, EncInfo *info, uint32_t *E, uint32_t estride,
                                                      uint32_t final_batch)
 {
     uint32_t n_rec = info->n_rec;
@@ -201,19 +217,21 @@ __global__ __launch_bounds__(256) void k_record_meta(const uint8_t *text, const 
             // validated before EOF is hit (parser.go:138-165), then it is dropped (parser.go:196-199)
             if (final_batch && info->status == 0) {
                 uint32_t have = n_lines - 4 * n_rec; // 0..3 complete lines
-                uint32_t s, l;
-                if (have >= 1) { line_span(text, ls, 4 * r, &s, &l); if (l == 0 || text[s] != '@') report_error(info, r, 0, FQZ_E_HDR_AT); }
-                if (have >= 3) { line_span(text, ls, 4 * r + 2, &s, &l); if (l == 0 || text[s] != '+') report_error(info, r, 1, FQZ_E_SEP_PLUS); }
+                if (have >= 1 && (lf[4 * r] >> 1) != 1) report_error(info, r, 0, FQZ_E_HDR_AT);
+                if (have >= 3 && (lf[4 * r + 2] >> 1) != 2) report_error(info, r, 1, FQZ_E_SEP_PLUS);
             }
             break;
         }
-        uint32_t s0, l0, s1, l1, s2, l2, s3, l3;
-        line_span(text, ls, 4 * r, &s0, &l0);
-        line_span(text, ls, 4 * r + 1, &s1, &l1);
-        line_span(text, ls, 4 * r + 2, &s2, &l2);
-        line_span(text, ls, 4 * r + 3, &s3, &l3);
-        if (l0 == 0 || text[s0] != '@') { report_error(info, r, 0, FQZ_E_HDR_AT); l0 = 1; }
-        if (l2 == 0 || text[s2] != '+') { report_error(info, r, 1, FQZ_E_SEP_PLUS); l2 = 1; }
+        const uint4 s4 = *(const uint4 *)(ls + 4 * r); // ls is 16-byte aligned
+        const uint32_t s_next = ls[4 * r + 4];
+        const uint32_t f4 = *(const uint32_t *)(lf + 4 * r), f_next = lf[4 * r + 4];
+        // length without '\n' and without one trailing '\r' (the flag implies a non-empty line)
+        uint32_t l0 = s4.y - 1 - s4.x - ((f4 >> 8) & 1);
+        uint32_t l1 = s4.z - 1 - s4.y - ((f4 >> 16) & 1);
+        uint32_t l2 = s4.w - 1 - s4.z - ((f4 >> 24) & 1);
+        uint32_t l3 = s_next - 1 - s4.w - (f_next & 1);
+        if (l0 == 0 || ((f4 >> 1) & 3) != 1) { report_error(info, r, 0, FQZ_E_HDR_AT); l0 = 1; }
+        if (l2 == 0 || ((f4 >> 17) & 3) != 2) { report_error(info, r, 1, FQZ_E_SEP_PLUS); l2 = 1; }
         if (l1 != l3) report_error(info, r, 2, FQZ_E_LEN_MISMATCH);
         uint32_t H = l0 - 1, P = l2 - 1;
         if (H > 65535u || P > 65535u) { report_error(info, r, 3, FQZ_E_FIELD_WRAP); H &= 0xFFFF; P &= 0xFFFF; }
@@ -221,6 +239,7 @@ __global__ __launch_bounds__(256) void k_record_meta(const uint8_t *text, const 
         E[(size_t)S_QUAL * estride + r] = l1;
         E[(size_t)S_HDR * estride + r] = 2 + H;
         E[(size_t)S_PLUS * estride + r] = 2 + P;
+        E[(size_t)S_NPOS * estride + r] = 2; // u16 count; the sequence stage adds 2 bytes per N position
     }
 }
 
@@ -248,7 +267,7 @@ __global__ void k_finish_detect(EncInfo *info)
 }
 
 // arena layout of the streams whose sizes are known after the first scans
-__global__ void k_plan1(EncInfo *info, const uint32_t *E, uint32_t estride, BlockPlan *plans, uint32_t rpb, size_t arena_cap)
+__global__ void k_plan1(EncInfo *info, const uint32_t *E, uint32_t estride, BlockPlan *plans, uint32_t rpb, size_t arena_cap, uint32_t main_cap)
 {
     if (threadIdx.x || blockIdx.x) return;
     if (info->error_key != ~0ull && info->status == 0) {
@@ -258,6 +277,7 @@ __global__ void k_plan1(EncInfo *info, const uint32_t *E, uint32_t estride, Bloc
     uint32_t n_rec = info->n_rec, n_blocks = info->n_blocks;
     if (info->status) { info->n_blocks = 0; info->n_rec = 0; return; }
     unsigned long long a = 0;
+    uint32_t chunks = 0;
     const int order[5] = {S_SEQ, S_QUAL, S_HDR, S_PLUS, S_LEN};
     for (uint32_t b = 0; b < n_blocks; b++) {
         BlockPlan *p = &plans[b];
@@ -271,11 +291,15 @@ __global__ void k_plan1(EncInfo *info, const uint32_t *E, uint32_t estride, Bloc
             p->a_off[s] = (uint32_t)a;
             a += (len + 15) & ~15u;
             info->stream_raw[s] += len;
+            p->chunk_base[s] = chunks; // main chunk ids: block by block, in this stream order
+            chunks += (len + FQZ_CHUNK - 1) / FQZ_CHUNK;
         }
         p->orig_seq = E[(size_t)S_QUAL * estride + r1] - E[(size_t)S_QUAL * estride + r0];
     }
-    if (a > arena_cap || a > 0xFFFFFFF0ull) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; info->n_rec = 0; return; }
+    if (a > arena_cap || a > 0xFFFFFFF0ull || chunks > main_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; info->n_rec = 0; return; }
     info->arena_used = (uint32_t)a;
+    info->n_main = chunks;
+    info->n_chunks = chunks;
 }
 
 // nPos arena + chunk table once the N counts are scanned
@@ -289,7 +313,7 @@ __global__ void k_plan2(EncInfo *info, const uint32_t *E, uint32_t estride, Bloc
     }
     uint32_t n_blocks = info->n_blocks;
     unsigned long long a = 0;
-    uint32_t chunks = 0;
+    uint32_t chunks = info->n_main;
     for (uint32_t b = 0; b < n_blocks; b++) {
         BlockPlan *p = &plans[b];
         uint32_t r0 = p->rec0, r1 = r0 + p->nrec;
@@ -298,12 +322,10 @@ __global__ void k_plan2(EncInfo *info, const uint32_t *E, uint32_t estride, Bloc
         p->a_off[S_NPOS] = (uint32_t)a;
         a += (len + 15) & ~15u;
         info->stream_raw[S_NPOS] += len;
-        for (int s = 0; s < FQZ_NS; s++) {
-            p->chunk_base[s] = chunks;
-            chunks += (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
-        }
+        p->chunk_base[S_NPOS] = chunks; // nPos chunk ids follow all main chunks
+        chunks += (len + FQZ_CHUNK - 1) / FQZ_CHUNK;
     }
-    if (a > npos_cap || chunks > chunk_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; chunks = 0; }
+    if (a > npos_cap || chunks > chunk_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; chunks = 0; info->n_main = 0; }
     info->npos_used = (uint32_t)a;
     info->n_chunks = chunks;
 }
@@ -371,6 +393,167 @@ __global__ __launch_bounds__(256) void k_split_seq(const uint8_t *text, const ui
             if (my_err) report_error(info, r, 4, FQZ_E_LONG_N);  // compress.go:477-488
             if (my_nn > 65535u) { report_error(info, r, 5, FQZ_E_FIELD_WRAP); my_nn = 0; }
             Enpos[r] = 2 + 2 * my_nn;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Piece-centric split (default): a wave takes 64 records; their bases, qualities, header and plus payloads are cut into
+// 16-byte pieces of ONE text line each, and every lane of every round handles one piece: 16 text bytes in (unaligned
+// 128-bit load), 4 packed / 16 delta-coded / 16 copied bytes out.  All lanes are busy whatever the read length and a
+// wave-wide load covers ~1 KiB of text.  The piece -> record map is a binary search over a wave scan of the per-record
+// piece counts (ds_bpermute, no LDS allocation).  The nPos payload (rare) is written later by k_npos_write.
+// ---------------------------------------------------------------------------------------------
+// smallest i with incl[i] > p, for p < incl[63]; every lane of the wave must call it
+__device__ __forceinline__ uint32_t piece_owner(uint32_t incl, uint32_t p)
+{
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = 32; step; step >>= 1) {
+        uint32_t v = (uint32_t)__shfl((int)incl, (int)(lo + step - 1), WAVE);
+        if (v <= p) lo += step;
+    }
+    return lo & 63;
+}
+
+__device__ __forceinline__ void store_piece(uint8_t *dst, const uint32_t w[4], uint32_t nb)
+{
+    if (nb == 16) store_u128_unaligned(dst, make_uint4(w[0], w[1], w[2], w[3]));
+    else
+        for (uint32_t b = 0; b < nb; b++) dst[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+}
+
+// 16 text bytes at text[off..off+16); bytes at or beyond n_text read as 0 (only the very last lines of the text get there)
+__device__ __forceinline__ void load_piece(const uint8_t *text, uint32_t off, uint32_t n_text, uint32_t w[4])
+{
+    if (off + 16 <= n_text) {
+        uint4 v = load_u128_unaligned(text + off);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+        w[0] = w[1] = w[2] = w[3] = 0;
+        for (uint32_t b = 0; b < 16 && off + b < n_text; b++) w[b >> 2] |= (uint32_t)text[off + b] << (8 * (b & 3));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text, uint32_t n_text, const uint32_t *__restrict__ ls, EncInfo *info,
+                                               uint32_t *E, uint32_t estride, const BlockPlan *__restrict__ plans, uint32_t rpb,
+                                               uint8_t *__restrict__ arena)
+{
+    const uint32_t n_rec = info->n_rec, qoff = info->qual_off;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    const uint32_t *Eseq = E + (size_t)S_SEQ * estride, *Equal = E + (size_t)S_QUAL * estride, *Ehdr = E + (size_t)S_HDR * estride;
+    const uint32_t *Eplus = E + (size_t)S_PLUS * estride;
+    uint32_t *Enpos = E + (size_t)S_NPOS * estride;
+    const uint32_t n_groups = (n_rec + 63) >> 6;
+    for (uint32_t g = wave; g < n_groups; g += nwaves) {
+        const uint32_t r = g * 64 + lane;
+        uint32_t s_hdr = 0, s_seq = 0, s_plus = 0, s_qual = 0, L = 0, H = 0, P = 0;
+        uint32_t d_seq = 0, d_qual = 0, d_hdr = 0, d_plus = 0;
+        if (r < n_rec) {
+            const uint4 l4 = *(const uint4 *)(ls + 4 * (size_t)r); // starts of the record's four lines
+            s_hdr = l4.x + 1; s_seq = l4.y; s_plus = l4.z + 1; s_qual = l4.w;
+            const BlockPlan *p = &plans[r / rpb];
+            const uint32_t r0 = p->rec0;
+            const uint32_t es = Eseq[r], eq = Equal[r], eh = Ehdr[r], ep = Eplus[r];
+            L = Equal[r + 1] - eq; H = Ehdr[r + 1] - eh - 2; P = Eplus[r + 1] - ep - 2;
+            d_seq = p->a_off[S_SEQ] + (es - Eseq[r0]);
+            d_qual = p->a_off[S_QUAL] + (eq - Equal[r0]);
+            d_hdr = p->a_off[S_HDR] + (eh - Ehdr[r0]);
+            d_plus = p->a_off[S_PLUS] + (ep - Eplus[r0]);
+            // ---- length: u32 L (one coalesced store per lane); record prefixes: u16 H, u16 P (compress.go:509-519)
+            *(uint32_t *)(arena + p->a_off[S_LEN] + 4 * (r - r0)) = L;
+            uint8_t *dh = arena + d_hdr, *dp = arena + d_plus;
+            dh[0] = (uint8_t)H; dh[1] = (uint8_t)(H >> 8);
+            dp[0] = (uint8_t)P; dp[1] = (uint8_t)(P >> 8);
+        }
+        const uint32_t pq = (L + 15) >> 4, ph = (H + 15) >> 4, pp = (P + 15) >> 4;
+        const uint32_t iq = wave_incl_scan(pq), ih = wave_incl_scan(ph), ip = wave_incl_scan(pp);
+        const uint32_t Tq = (uint32_t)RL(iq, 63), Th = (uint32_t)RL(ih, 63), Tp = (uint32_t)RL(ip, 63);
+
+        // ---- bases: 16 bases -> 4 packed bytes (sequence.go:139-184); N counts go to E[nPos] (compress.go:477-488)
+        for (uint32_t base = 0; base < Tq; base += WAVE) {
+            const uint32_t p = base + lane;
+            const bool on = p < Tq;
+            const uint32_t i = piece_owner(iq, on ? p : 0);
+            const uint32_t k = p - (uint32_t)__shfl((int)(iq - pq), (int)i, WAVE);
+            const uint32_t Li = (uint32_t)__shfl((int)L, (int)i, WAVE), src = (uint32_t)__shfl((int)s_seq, (int)i, WAVE);
+            const uint32_t dst = (uint32_t)__shfl((int)d_seq, (int)i, WAVE);
+            if (on) {
+                uint32_t x[4];
+                load_piece(text, src + 16 * k, n_text, x);
+                const uint32_t have = Li - 16 * k < 16 ? Li - 16 * k : 16;
+                uint32_t out = 0, nn = 0, beyond = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t v = x[q], in_read = 0x80808080u;
+                    if (have < 4u * q + 4) { // bytes past the read pack as 0
+                        const uint32_t hv = have > 4u * q ? have - 4u * q : 0;
+                        v = hv ? v & ((1u << (8 * hv)) - 1) : 0;
+                        in_read = hv ? in_read >> (8 * (4 - hv)) : 0;
+                    }
+                    const uint32_t vmask = acgt_mask(v);
+                    const uint32_t invalid = ~vmask & in_read;
+                    out |= pack4(v, vmask) << (8 * q);
+                    if (invalid) {
+                        const uint32_t b0 = 16 * k + 4 * q;
+                        if (b0 + 3 < FQZ_MAX_SEQUENCE_LENGTH) nn += __popc(invalid);
+                        else
+                            for (uint32_t z = 0; z < 4; z++)
+                                if (invalid & (0x80u << (8 * z))) { if (b0 + z < FQZ_MAX_SEQUENCE_LENGTH) nn++; else beyond = 1; }
+                    }
+                }
+                const uint32_t nb = (have + 3) >> 2;
+                uint8_t *o = arena + dst + 4 * k;
+                if (nb == 4) store_u32_unaligned(o, out);
+                else
+                    for (uint32_t b = 0; b < nb; b++) o[b] = (uint8_t)(out >> (8 * b));
+                if (beyond) report_error(info, g * 64 + i, 4, FQZ_E_LONG_N);
+                if (nn) atomicAdd(&Enpos[g * 64 + i], 2 * nn);
+            }
+        }
+        // ---- quality: q'[0] = q[0]-off, q'[j] = q[j]-q[j-1], restarting per record (quality.go:53-103)
+        for (uint32_t base = 0; base < Tq; base += WAVE) {
+            const uint32_t p = base + lane;
+            const bool on = p < Tq;
+            const uint32_t i = piece_owner(iq, on ? p : 0);
+            const uint32_t k = p - (uint32_t)__shfl((int)(iq - pq), (int)i, WAVE);
+            const uint32_t Li = (uint32_t)__shfl((int)L, (int)i, WAVE), src = (uint32_t)__shfl((int)s_qual, (int)i, WAVE);
+            const uint32_t dst = (uint32_t)__shfl((int)d_qual, (int)i, WAVE);
+            if (on) {
+                uint32_t x[4], w[4];
+                uint32_t prev = k ? text[src + 16 * k - 1] : qoff;
+                load_piece(text, src + 16 * k, n_text, x);
+#pragma unroll
+                for (int q = 0; q < 4; q++) { w[q] = sub_bytes(x[q], (x[q] << 8) | (prev & 0xFF)); prev = x[q] >> 24; }
+                store_piece(arena + dst + 16 * k, w, Li - 16 * k < 16 ? Li - 16 * k : 16);
+            }
+        }
+        // ---- header and plus payloads (without '@' / '+'), after their u16 length
+        for (uint32_t base = 0; base < Th; base += WAVE) {
+            const uint32_t p = base + lane;
+            const bool on = p < Th;
+            const uint32_t i = piece_owner(ih, on ? p : 0);
+            const uint32_t k = p - (uint32_t)__shfl((int)(ih - ph), (int)i, WAVE);
+            const uint32_t Hi = (uint32_t)__shfl((int)H, (int)i, WAVE), src = (uint32_t)__shfl((int)s_hdr, (int)i, WAVE);
+            const uint32_t dst = (uint32_t)__shfl((int)d_hdr, (int)i, WAVE);
+            if (on) {
+                uint32_t x[4];
+                load_piece(text, src + 16 * k, n_text, x);
+                store_piece(arena + dst + 2 + 16 * k, x, Hi - 16 * k < 16 ? Hi - 16 * k : 16);
+            }
+        }
+        for (uint32_t base = 0; base < Tp; base += WAVE) {
+            const uint32_t p = base + lane;
+            const bool on = p < Tp;
+            const uint32_t i = piece_owner(ip, on ? p : 0);
+            const uint32_t k = p - (uint32_t)__shfl((int)(ip - pp), (int)i, WAVE);
+            const uint32_t Pi = (uint32_t)__shfl((int)P, (int)i, WAVE), src = (uint32_t)__shfl((int)s_plus, (int)i, WAVE);
+            const uint32_t dst = (uint32_t)__shfl((int)d_plus, (int)i, WAVE);
+            if (on) {
+                uint32_t x[4];
+                load_piece(text, src + 16 * k, n_text, x);
+                store_piece(arena + dst + 2 + 16 * k, x, Pi - 16 * k < 16 ? Pi - 16 * k : 16);
+            }
         }
     }
 }
@@ -468,26 +651,48 @@ __global__ __launch_bounds__(256) void k_split_rest(const uint8_t *text, const u
 // The construction is the deterministic "FQZ-H1" profile specified in DESIGN.md
 // and restated on the CPU in oracle/fqz_entropy.c; outputs are byte-identical.
 // ===========================================================================
-__global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const BlockPlan *plans, const uint8_t *arena, const uint8_t *npos_arena,
-                                                 uint8_t *slots, uint32_t *csize, int dbg_stop, unsigned long long *stamps)
+// chunk id -> (block, stream, chunk index inside the stream).  Main chunks are numbered block by block in the
+// order seq, qual, headers, plus, lengths; the nPos chunks of all blocks follow (their count is only known
+// after the sequence stage has counted the N bases).
+__device__ __forceinline__ void locate_chunk(const EncInfo *info, const BlockPlan *plans, uint32_t chunk, uint32_t *bidx, int *stream, uint32_t *cidx)
 {
-    __shared__ __attribute__((aligned(16))) EntropyLds S;
-    const uint32_t chunk = blockIdx.x;
-    if (chunk >= info->n_chunks) return;
-    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    if (stamps) { stamps += (size_t)chunk * 16; if (t == 0) stamps[0] = __builtin_amdgcn_s_memtime(); }
-
-    if (t == 0) {
-        uint32_t nb = info->n_blocks, lo = 0, hi = nb;
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (plans[mid].chunk_base[0] <= chunk) lo = mid; else hi = mid; }
-        const BlockPlan *p = &plans[lo];
-        int s = 0;
-        for (int k = 0; k < FQZ_NS; k++) {
+    const uint32_t nb = info->n_blocks;
+    const bool is_npos = chunk >= info->n_main;
+    const int key = is_npos ? S_NPOS : S_SEQ;
+    uint32_t lo = 0, hi = nb;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (plans[mid].chunk_base[key] <= chunk) lo = mid; else hi = mid; }
+    const BlockPlan *p = &plans[lo];
+    int s = S_NPOS;
+    if (!is_npos) {
+        const int order[5] = {S_SEQ, S_QUAL, S_HDR, S_PLUS, S_LEN};
+        s = S_SEQ;
+        for (int q = 0; q < 5; q++) {
+            int k = order[q];
             uint32_t nch = (p->len[k] + FQZ_CHUNK - 1) / FQZ_CHUNK;
             if (nch && chunk >= p->chunk_base[k] && chunk < p->chunk_base[k] + nch) s = k;
         }
+    }
+    *bidx = lo;
+    *stream = s;
+    *cidx = chunk - p->chunk_base[s];
+}
+
+// chunk source = a pre-entropy stream materialised in HBM (all streams in the unfused pipeline, nPos always)
+__global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const BlockPlan *plans, const uint8_t *arena, const uint8_t *npos_arena,
+                                                 uint8_t *slots, uint32_t *csize, int only_npos, int dbg_stop, unsigned long long *stamps)
+{
+    __shared__ __attribute__((aligned(16))) EntropyLds S;
+    const uint32_t chunk = blockIdx.x + (only_npos ? info->n_main : 0u);
+    if (chunk >= info->n_chunks) return;
+    const uint32_t t = threadIdx.x;
+    if (stamps) { stamps += (size_t)chunk * 16; if (t == 0) stamps[0] = __builtin_amdgcn_s_memtime(); }
+
+    if (t == 0) {
+        uint32_t b, c;
+        int s;
+        locate_chunk(info, plans, chunk, &b, &s, &c);
+        const BlockPlan *p = &plans[b];
         if (stamps) stamps[15] = (unsigned long long)s;
-        uint32_t c = chunk - p->chunk_base[s];
         uint32_t off = c * FQZ_CHUNK;
         uint32_t m = p->len[s] - off < FQZ_CHUNK ? p->len[s] - off : FQZ_CHUNK;
         S.misc[0] = p->a_off[s] + off;
@@ -509,50 +714,396 @@ __global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const Bloc
 }
 
 // ===========================================================================
+// Fused path: the chunk is built straight from the FASTQ text into LDS — the six-stream split of
+// compressBlockWithBuffers (compress.go:474-520) never touches HBM.
+// ===========================================================================
+// first record that owns a byte of each main chunk (one thread per chunk; binary search over the scanned offsets)
+__global__ __launch_bounds__(256) void k_chunk_map(const EncInfo *info, const BlockPlan *plans, const uint32_t *E, uint32_t estride, uint32_t *chunk_rec)
+{
+    const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
+    if (chunk >= info->n_main) return;
+    uint32_t b, c;
+    int s;
+    locate_chunk(info, plans, chunk, &b, &s, &c);
+    const BlockPlan *p = &plans[b];
+    if (s == S_LEN) { chunk_rec[chunk] = p->rec0 + c * (FQZ_CHUNK / 4); return; }
+    const uint32_t *Es = E + (size_t)s * estride;
+    const uint32_t base = Es[p->rec0], c0 = c * FQZ_CHUNK;
+    uint32_t lo = p->rec0, hi = p->rec0 + p->nrec; // first r in [lo, hi) whose end lies beyond c0
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (Es[mid + 1] - base > c0) hi = mid; else lo = mid + 1; }
+    chunk_rec[chunk] = lo;
+}
+
+__device__ __forceinline__ void store_lds_bytes(uint8_t *dst, uint32_t v, uint32_t have)
+{
+    if (have == 4) store_u32_unaligned(dst, v); // ds_write_b32 at any byte offset (unaligned DS access is enabled on gfx950)
+    else for (uint32_t j = 0; j < have; j++) dst[j] = (uint8_t)(v >> (8 * j));
+}
+
+__global__ __launch_bounds__(256) void k_entropy_fused(const uint8_t *text, uint32_t n_text, const uint32_t *ls, EncInfo *info, uint32_t *E, uint32_t estride,
+                                                       const BlockPlan *plans, const uint32_t *chunk_rec, uint8_t *slots, uint32_t *csize,
+                                                       int dbg_stop, unsigned long long *stamps)
+{
+    __shared__ __attribute__((aligned(16))) EntropyLds S;
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= info->n_main) return;
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    if (stamps) { stamps += (size_t)chunk * 16; if (t == 0) stamps[0] = __builtin_amdgcn_s_memtime(); }
+    if (t == 0) {
+        uint32_t b, c;
+        int s;
+        locate_chunk(info, plans, chunk, &b, &s, &c);
+        const BlockPlan *p = &plans[b];
+        if (stamps) stamps[15] = (unsigned long long)s;
+        uint32_t off = c * FQZ_CHUNK;
+        uint32_t m = p->len[s] - off < FQZ_CHUNK ? p->len[s] - off : FQZ_CHUNK;
+        S.misc[0] = b;
+        S.misc[1] = m;
+        S.misc[2] = (off + m == p->len[s]);
+        S.misc[3] = (uint32_t)s;
+        S.misc[24] = off;
+        S.misc[25] = chunk_rec[chunk];
+    }
+    uint32_t *hist_all = lds_hist(S);
+    for (uint32_t i = t; i < 4 * 256; i += 256) hist_all[i] = 0;
+    for (uint32_t i = t; i < FQZ_CHUNK / 16 + 1; i += 256) *(uint4 *)&S.chunk[4 * i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t m = S.misc[1], last = S.misc[2], c0 = S.misc[24], r_first = S.misc[25];
+    const int s = (int)S.misc[3];
+    const BlockPlan *p = &plans[S.misc[0]];
+    uint8_t *chunk8 = (uint8_t *)S.chunk;
+    const uint32_t *Equal = E + (size_t)S_QUAL * estride;
+
+    if (s == S_LEN) {
+        // ---- lengths: u32 L per record (compress.go:501)
+        for (uint32_t i = t; 4 * i < m; i += 256) { uint32_t r = r_first + i; S.chunk[i] = Equal[r + 1] - Equal[r]; }
+    } else if (s == S_PLUS && p->len[S_PLUS] == 2 * p->nrec) {
+        // every plus line is bare: the stream is all zero length prefixes, and the chunk buffer is already zero
+    } else {
+        const uint32_t *Es = E + (size_t)s * estride;
+        const uint32_t rec_end = p->rec0 + p->nrec, base = Es[p->rec0];
+        const uint32_t line = s == S_SEQ ? 1 : (s == S_QUAL ? 3 : (s == S_HDR ? 0 : 2));
+        const uint32_t qoff = info->qual_off;
+        // ---- record table of the chunk in LDS (the staging buffer is free until the histogram): for record i of the
+        // chunk, rel[i] = chunk-relative position of its first stream byte (rel[0] <= 0), srco[i] = text offset of its
+        // line (payload start for headers / plus), aux[i] = read length (seq only), pc[i] = number of 16-byte pieces
+        // of the records before it.  rel[cnt] / pc[cnt] are the end sentinels.
+        constexpr uint32_t TCAP = 510;
+        int *rel = (int *)S.out;
+        uint32_t *srco = S.out + (TCAP + 2), *aux = S.out + 2 * (TCAP + 2), *pc = S.out + 3 * (TCAP + 2);
+        const uint32_t cnt = rec_end - r_first < TCAP ? rec_end - r_first : TCAP;
+        uint32_t total_pieces;
+        {
+            uint32_t np[2] = {0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; h++) { // thread t owns records 2t and 2t+1 so that a workgroup scan yields prefix order
+                const uint32_t i = 2 * t + h;
+                if (i <= cnt) {
+                    const uint32_t r = r_first + i;
+                    const uint32_t e0 = Es[r];
+                    rel[i] = (int)(e0 - base - c0);
+                    if (i < cnt) {
+                        srco[i] = ls[4 * r + line] + ((s == S_HDR || s == S_PLUS) ? 1u : 0u);
+                        if (s == S_SEQ) aux[i] = Equal[r + 1] - Equal[r];
+                        np[h] = (Es[r + 1] - e0 + 15) >> 4;
+                    }
+                }
+            }
+            const uint32_t ex = block_excl_scan_256(np[0] + np[1], S.misc + 26, &total_pieces);
+            if (2 * t <= cnt) pc[2 * t] = ex;
+            if (2 * t + 1 <= cnt) pc[2 * t + 1] = ex + np[0];
+        }
+        __syncthreads();
+        const bool table_ok = rel[cnt] >= (int)m; // the table reaches the end of the chunk
+        if (table_ok) {
+            // ---- a lane handles one 16-byte piece of ONE record (pieces never straddle records): dword loads only, all
+            // of a round's loads issued before any is used, results stored at the piece's (unaligned) LDS position
+            constexpr int PB = 2; // pieces per lane per round
+            for (uint32_t p0 = t; p0 < total_pieces; p0 += 256 * PB) {
+                uint32_t pi[PB], pk[PB];
+                bool pv[PB];
+#pragma unroll
+                for (int u = 0; u < PB; u++) {
+                    const uint32_t pp = p0 + 256 * u;
+                    pv[u] = pp < total_pieces;
+                    pi[u] = 0; pk[u] = 0;
+                    if (pv[u]) {
+                        uint32_t lo = 0, hi = cnt; // last record i with pc[i] <= pp (records without pieces share a value)
+                        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (pc[mid] <= pp) lo = mid; else hi = mid; }
+                        pi[u] = lo;
+                        pk[u] = pp - pc[lo];
+                    }
+                }
+                if (s == S_SEQ) {
+                    // ---- bases: piece k = packed bytes 16k..16k+15 = bases 64k..64k+63 (sequence.go:139-184)
+                    uint32_t X[PB][16];
+#pragma unroll
+                    for (int u = 0; u < PB; u++)
+#pragma unroll
+                        for (int bb = 0; bb < 16; bb++) X[u][bb] = 0;
+#pragma unroll
+                    for (int u = 0; u < PB; u++) {
+                        if (!pv[u]) continue;
+                        const uint32_t L = aux[pi[u]];
+                        const uint8_t *src = text + srco[pi[u]] + 64 * pk[u]; // "\n+...\n<quality>" follows: a read never leaves the text
+#pragma unroll
+                        for (int bb = 0; bb < 16; bb++) if (64 * pk[u] + 4 * bb < L) X[u][bb] = load_u32_unaligned(src + 4 * bb);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PB; u++) {
+                        if (!pv[u]) continue;
+                        const uint32_t i = pi[u], L = aux[i], k0 = 16 * pk[u];
+                        const int dst = rel[i] + (int)k0;
+                        const uint32_t plen = (L + 3) >> 2, nb = plen - k0 < 16 ? plen - k0 : 16;
+                        uint32_t w[4] = {0, 0, 0, 0}, nn = 0, beyond = 0;
+#pragma unroll
+                        for (int bb = 0; bb < 16; bb++) {
+                            const uint32_t k = k0 + (uint32_t)bb;
+                            if (k >= plen || dst + bb < 0 || dst + bb >= (int)m) continue; // outside the read or the chunk (a neighbour chunk counts it)
+                            uint32_t x = X[u][bb], have = L - 4 * k, in_read = 0x80808080u;
+                            if (have < 4) { x &= (1u << (8 * have)) - 1; in_read >>= 8 * (4 - have); }
+                            uint32_t vmask = acgt_mask(x);
+                            uint32_t invalid = ~vmask & in_read;
+                            w[bb >> 2] |= pack4(x, vmask) << (8 * (bb & 3));
+                            if (invalid) {
+                                if (4 * k + 3 < FQZ_MAX_SEQUENCE_LENGTH) nn += __popc(invalid);
+                                else
+                                    for (uint32_t z = 0; z < 4; z++)
+                                        if (invalid & (0x80u << (8 * z))) { if (4 * k + z < FQZ_MAX_SEQUENCE_LENGTH) nn++; else beyond = 1; }
+                            }
+                        }
+                        if (beyond) report_error(info, r_first + i, 4, FQZ_E_LONG_N); // compress.go:477-488
+                        if (nn) atomicAdd(&E[(size_t)S_NPOS * estride + r_first + i], 2 * nn);
+                        if (dst >= 0 && dst + 16 <= (int)m && nb == 16) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) store_u32_unaligned(chunk8 + dst + 4 * q, w[q]);
+                        } else {
+                            for (uint32_t bb = 0; bb < nb; bb++)
+                                if (dst + (int)bb >= 0 && dst + (int)bb < (int)m) chunk8[dst + (int)bb] = (uint8_t)(w[bb >> 2] >> (8 * (bb & 3)));
+                        }
+                    }
+                } else {
+                    // ---- quality (delta, quality.go:53-103) and headers / plus ([u16 H][H bytes], compress.go:514-519)
+                    const int pre = s == S_QUAL ? 0 : 2; // stream bytes that precede the text payload of a record
+                    uint32_t X[PB][4], PV[PB];
+#pragma unroll
+                    for (int u = 0; u < PB; u++) {
+                        PV[u] = qoff;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) X[u][q] = 0;
+                        if (!pv[u]) continue;
+                        const uint32_t so = srco[pi[u]];
+                        const int off = 16 * (int)pk[u] - pre; // payload offset of the piece's first byte (negative inside the prefix)
+                        const int nb = rel[pi[u] + 1] - rel[pi[u]] - 16 * (int)pk[u]; // stream bytes left in the record
+                        if ((int)so + off >= 0 && so + (uint32_t)(off + 16) <= n_text) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) X[u][q] = load_u32_unaligned(text + so + off + 4 * q);
+                        } else { // first / last bytes of the whole text: byte loads
+                            for (int bb = 0; bb < 16 && bb < nb; bb++)
+                                if ((int)so + off + bb >= 0 && so + (uint32_t)(off + bb) < n_text) X[u][bb >> 2] |= (uint32_t)text[so + off + bb] << (8 * (bb & 3));
+                        }
+                        if (s == S_QUAL && pk[u]) PV[u] = text[so + off - 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < PB; u++) {
+                        if (!pv[u]) continue;
+                        const uint32_t i = pi[u];
+                        const int rlen = rel[i + 1] - rel[i], k0 = 16 * (int)pk[u];
+                        const int dst = rel[i] + k0, nb = rlen - k0 < 16 ? rlen - k0 : 16;
+                        uint32_t w[4];
+                        if (s == S_QUAL) {
+                            uint32_t prev = PV[u];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) { w[q] = sub_bytes(X[u][q], (X[u][q] << 8) | (prev & 0xFF)); prev = X[u][q] >> 24; }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) w[q] = X[u][q];
+                            if (k0 == 0) w[0] = (w[0] & 0xFFFF0000u) | ((uint32_t)(rlen - 2) & 0xFFFFu); // the u16 length prefix
+                        }
+                        if (dst >= 0 && dst + 16 <= (int)m && nb == 16) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) store_u32_unaligned(chunk8 + dst + 4 * q, w[q]);
+                        } else {
+                            for (int bb = 0; bb < nb; bb++)
+                                if (dst + bb >= 0 && dst + bb < (int)m) chunk8[dst + bb] = (uint8_t)(w[bb >> 2] >> (8 * (bb & 3)));
+                        }
+                    }
+                }
+            }
+        } else {
+            // ---- more records than the table holds (very short reads): a wave walks the records one by one
+            uint32_t *m_src = S.keys;
+            int *m_start = (int *)S.sorted;
+            uint32_t *m_len = S.ctab;
+            for (uint32_t r_batch = r_first;; r_batch += 256) {
+                const uint32_t r = r_batch + t;
+                int valid = 0;
+                if (r < rec_end) {
+                    uint32_t e0 = Es[r] - base;
+                    valid = e0 < c0 + m;
+                    m_start[t] = (int)(e0 - c0);
+                    m_len[t] = s == S_SEQ ? Equal[r + 1] - Equal[r] : Es[r + 1] - Es[r];
+                    m_src[t] = ls[4 * r + line] + ((s == S_HDR || s == S_PLUS) ? 1u : 0u);
+                }
+                const int n_valid = __syncthreads_count(valid);
+                for (int i = (int)wave; i < n_valid; i += 4) {
+                    const int S0 = m_start[i];
+                    const uint32_t len = m_len[i];
+                    const uint8_t *src = text + m_src[i];
+                    if (s == S_QUAL) {
+                        const int j_lo = S0 < 0 ? -S0 : 0, j_hi = (int)len < (int)m - S0 ? (int)len : (int)m - S0;
+                        for (int j = j_lo + 4 * (int)lane; ; j += 4 * WAVE) {
+                            if (!__ballot(j < j_hi)) break;
+                            uint32_t x = 0, have = 0;
+                            if (j < j_hi) {
+                                have = (uint32_t)(j_hi - j < 4 ? j_hi - j : 4);
+                                if (m_src[i] + (uint32_t)j + 4 <= n_text) x = load_u32_unaligned(src + j);
+                                else for (uint32_t k = 0; k < have; k++) x |= (uint32_t)src[j + k] << (8 * k);
+                            }
+                            uint32_t prev = __shfl_up(x >> 24, 1, WAVE);
+                            if (lane == 0) prev = j ? src[j - 1] : qoff;
+                            if (have) store_lds_bytes(chunk8 + S0 + j, sub_bytes(x, (x << 8) | (prev & 0xFF)), have);
+                        }
+                    } else if (s == S_SEQ) {
+                        const int plen = (int)((len + 3) >> 2);
+                        const int k_lo = S0 < 0 ? -S0 : 0, k_hi = plen < (int)m - S0 ? plen : (int)m - S0;
+                        uint32_t nn = 0, beyond = 0;
+                        for (int k = k_lo + (int)lane; k < k_hi; k += WAVE) {
+                            uint32_t x = load_u32_unaligned(src + 4 * k);
+                            uint32_t have = len - 4 * (uint32_t)k, in_read = 0x80808080u;
+                            if (have < 4) { x &= (1u << (8 * have)) - 1; in_read >>= 8 * (4 - have); }
+                            uint32_t vmask = acgt_mask(x);
+                            uint32_t invalid = ~vmask & in_read;
+                            chunk8[S0 + k] = (uint8_t)pack4(x, vmask);
+                            if (invalid) {
+                                if (4 * (uint32_t)k + 3 < FQZ_MAX_SEQUENCE_LENGTH) nn += __popc(invalid);
+                                else
+                                    for (uint32_t q = 0; q < 4; q++)
+                                        if (invalid & (0x80u << (8 * q))) { if (4 * (uint32_t)k + q < FQZ_MAX_SEQUENCE_LENGTH) nn++; else beyond = 1; }
+                            }
+                        }
+                        if (__ballot(nn | beyond)) {
+                            nn = wave_sum(nn);
+                            beyond = wave_sum(beyond);
+                            if (lane == 0) {
+                                const uint32_t rr = r_batch + (uint32_t)i;
+                                if (beyond) report_error(info, rr, 4, FQZ_E_LONG_N);
+                                if (nn) atomicAdd(&E[(size_t)S_NPOS * estride + rr], 2 * nn);
+                            }
+                        }
+                    } else {
+                        const int j_lo = S0 < 0 ? -S0 : 0, j_hi = (int)len < (int)m - S0 ? (int)len : (int)m - S0;
+                        const uint32_t H = len - 2;
+                        for (int j = j_lo + (int)lane; j < j_hi; j += WAVE) chunk8[S0 + j] = j < 2 ? (uint8_t)(H >> (8 * j)) : src[j - 2];
+                    }
+                }
+                __syncthreads();
+                if (n_valid < 256) break;
+            }
+        }
+    }
+    __syncthreads();
+    histogram_from_lds(S, m);
+    __syncthreads();
+    entropy_encode_chunk(S, m, last, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
+}
+
+// nPos stream: u16 count + u16 positions per record (compress.go:495-498) into the nPos arena; a wave owns 64 records
+__global__ __launch_bounds__(256) void k_npos_write(const uint8_t *text, const uint32_t *ls, EncInfo *info, const uint32_t *E, uint32_t estride,
+                                                    const BlockPlan *plans, uint32_t rpb, uint8_t *npos_arena)
+{
+    const uint32_t n_rec = info->n_rec;
+    if (info->status) return;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    const uint32_t *Equal = E + (size_t)S_QUAL * estride, *Enpos = E + (size_t)S_NPOS * estride;
+    const uint32_t n_groups = (n_rec + 63) >> 6;
+    for (uint32_t g = wave; g < n_groups; g += nwaves) {
+        const uint32_t r = g * 64 + lane;
+        uint32_t s_seq = 0, L = 0, NN = 0, d_npos = 0;
+        if (r < n_rec) {
+            const BlockPlan *p = &plans[r / rpb];
+            uint32_t en = Enpos[r];
+            NN = (Enpos[r + 1] - en - 2) >> 1;
+            d_npos = p->a_off[S_NPOS] + (en - Enpos[p->rec0]);
+            uint8_t *dn = npos_arena + d_npos;
+            if (NN > 65535u) { report_error(info, r, 5, FQZ_E_FIELD_WRAP); NN = 0; }
+            dn[0] = (uint8_t)NN; dn[1] = (uint8_t)(NN >> 8);
+            if (NN) { s_seq = ls[4 * r + 1]; L = Equal[r + 1] - Equal[r]; }
+        }
+        unsigned long long todo = __ballot(NN != 0);
+        while (todo) {
+            const int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t Li = (uint32_t)RL(L, i);
+            const uint8_t *sq = text + (uint32_t)RL(s_seq, i);
+            uint8_t *dst = npos_arena + (uint32_t)RL(d_npos, i);
+            uint32_t limit = Li < FQZ_MAX_SEQUENCE_LENGTH ? Li : FQZ_MAX_SEQUENCE_LENGTH, run = 0;
+            for (uint32_t base = 0; base < limit; base += WAVE) {
+                uint32_t k = base + lane;
+                bool inv = false;
+                if (k < limit) inv = (acgt_mask((uint32_t)sq[k] * 0x01010101u) & 0x80u) == 0;
+                unsigned long long mk = __ballot(inv);
+                if (inv) {
+                    uint32_t w = run + __popcll(mk & ((1ull << lane) - 1));
+                    dst[2 + 2 * w] = (uint8_t)k;
+                    dst[3 + 2 * w] = (uint8_t)(k >> 8);
+                }
+                run += __popcll(mk);
+            }
+        }
+    }
+}
+
+// ===========================================================================
 // K7 framing (container.go:97-109, compress.go:532-552) + compaction
 // ===========================================================================
 __device__ __forceinline__ void put_le32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 
 // csize has been scanned in place (exclusive prefix, total at [n_chunks])
-// one 256-thread workgroup, one thread per block: a block starts at
-//   36*b + 10*(non-empty frames before b) + (compressed chunk bytes before b)
+// one 256-thread workgroup, one thread per block: block size = 36 + its six frames, offsets by a workgroup scan
 __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap)
 {
     __shared__ uint32_t sh[4];
-    __shared__ unsigned long long s_total;
     if (blockIdx.x) return;
-    const uint32_t n_blocks = info->n_blocks, t = threadIdx.x;
-    uint32_t carry = 0; // non-empty frames in the blocks of earlier strips
+    const uint32_t t = threadIdx.x;
+    if (t == 0 && info->error_key != ~0ull && info->status == 0) { // errors raised after the plan kernels (nPos count overflow)
+        info->status = -(int32_t)(info->error_key & 31);
+        info->error_record = (uint32_t)(info->error_key >> 8);
+    }
+    __syncthreads();
+    const uint32_t n_blocks = info->status ? 0u : info->n_blocks;
+    unsigned long long carry = 0; // bytes of the blocks of earlier strips
     unsigned long long comp[FQZ_NS] = {0, 0, 0, 0, 0, 0};
     for (uint32_t base = 0; base < n_blocks; base += 256) {
         const uint32_t b = base + t;
         BlockPlan *p = b < n_blocks ? &plans[b] : nullptr;
-        uint32_t nonempty = 0;
-        if (p) for (int s = 0; s < FQZ_NS; s++) nonempty += p->len[s] != 0;
-        uint32_t tot;
-        uint32_t before = carry + block_excl_scan_256(nonempty, sh, &tot);
-        carry += tot;
+        uint32_t flen[FQZ_NS] = {0, 0, 0, 0, 0, 0}, size = 0;
         if (p) {
-            unsigned long long start = 36ull * b + 10ull * before + cpre[p->chunk_base[0]];
-            unsigned long long pos = start + 36;
+            size = 36;
             for (int s = 0; s < FQZ_NS; s++) {
                 uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
-                uint32_t flen = nch ? 10 + (cpre[p->chunk_base[s] + nch] - cpre[p->chunk_base[s]]) : 0;
+                flen[s] = nch ? 10 + (cpre[p->chunk_base[s] + nch] - cpre[p->chunk_base[s]]) : 0;
+                size += flen[s];
+            }
+        }
+        uint32_t tot;
+        const unsigned long long start = carry + block_excl_scan_256(size, sh, &tot);
+        carry += tot;
+        if (p) {
+            unsigned long long pos = start + 36;
+            for (int s = 0; s < FQZ_NS; s++) {
                 p->frame_off[s] = (uint32_t)pos;
-                p->frame_len[s] = flen;
-                pos += flen;
-                comp[s] += flen;
+                p->frame_len[s] = flen[s];
+                pos += flen[s];
+                comp[s] += flen[s];
             }
             p->out_off = (uint32_t)start;
-            p->out_len = (uint32_t)(pos - start);
-            if (b + 1 == n_blocks) s_total = pos;
+            p->out_len = size;
         }
         __syncthreads();
     }
     for (int s = 0; s < FQZ_NS; s++) if (comp[s]) atomicAdd(&info->stream_comp[s], comp[s]);
-    if (!n_blocks && t == 0) s_total = 0;
-    __syncthreads();
-    const unsigned long long total = s_total;
+    const unsigned long long total = carry; // identical in every thread
     if (t == 0) {
         info->out_len = total;
         if ((total > out_cap || total > 0xFFFFFFF0ull) && !info->status) info->status = FQZ_E_DST_SMALL;
@@ -590,14 +1141,10 @@ __global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const Bloc
     if (info->status || chunk >= info->n_chunks) return;
     const uint32_t t = threadIdx.x;
     if (t == 0) {
-        uint32_t nb = info->n_blocks, lo = 0, hi = nb;
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (plans[mid].chunk_base[0] <= chunk) lo = mid; else hi = mid; }
-        const BlockPlan *p = &plans[lo];
-        int s = 0;
-        for (int k = 0; k < FQZ_NS; k++) {
-            uint32_t nch = (p->len[k] + FQZ_CHUNK - 1) / FQZ_CHUNK;
-            if (nch && chunk >= p->chunk_base[k] && chunk < p->chunk_base[k] + nch) s = k;
-        }
+        uint32_t b, c;
+        int s;
+        locate_chunk(info, plans, chunk, &b, &s, &c);
+        const BlockPlan *p = &plans[b];
         sh[0] = p->frame_off[s] + 10 + (cpre[chunk] - cpre[p->chunk_base[s]]);
         sh[1] = cpre[chunk + 1] - cpre[chunk];
     }
@@ -678,18 +1225,23 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     e.block_cap = e.rec_cap / rpb + 2;
     e.arena_cap = (size_t)n + 4ull * e.rec_cap + 96ull * e.block_cap + 4096;
     e.npos_cap = (size_t)n + 2ull * e.rec_cap + 16ull * e.block_cap + 4096;
-    size_t chunk_cap = (e.arena_cap + e.npos_cap) / FQZ_CHUNK + 6ull * e.block_cap + 8;
+    const size_t main_cap = e.arena_cap / FQZ_CHUNK + 5ull * e.block_cap + 8;      // seq / qual / headers / plus / lengths chunks
+    const size_t npos_chunk_cap = e.npos_cap / FQZ_CHUNK + 1ull * e.block_cap + 8; // nPos chunks
+    const size_t chunk_cap = main_cap + npos_chunk_cap;
     if (chunk_cap > 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
     e.chunk_cap = (uint32_t)chunk_cap;
+    const bool fused = !e.unfused;
     const uint32_t estride = e.rec_cap + 1;
 
     int rc;
     if ((rc = e.info.ensure(sizeof(EncInfo)))) return rc;
     if ((rc = e.tile_cnt.ensure(4ull * (e.n_tiles + 2)))) return rc;
-    if ((rc = e.ls.ensure(4ull * (e.line_cap + 2)))) return rc;
+    if ((rc = e.ls.ensure(4ull * (e.line_cap + 8)))) return rc;
+    if ((rc = e.lf.ensure(e.line_cap + 8))) return rc;
     if ((rc = e.E.ensure(4ull * 5 * estride))) return rc;
     if ((rc = e.plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
-    if ((rc = e.arena.ensure(e.arena_cap + 64))) return rc;
+    if (!fused && (rc = e.arena.ensure(e.arena_cap + 64))) return rc; // only the unfused pipeline materialises these streams
+    if (fused && (rc = e.chunk_rec.ensure(4ull * (main_cap + 1)))) return rc;
     if ((rc = e.npos.ensure(e.npos_cap + 64))) return rc;
     if ((rc = e.slots.ensure((size_t)e.chunk_cap * FQZ_SLOT))) return rc;
     if ((rc = e.csize.ensure(4ull * (e.chunk_cap + 2)))) return rc;
@@ -700,10 +1252,12 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
     if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
 
+    e.streams_valid = !fused;
     e.d_text = d_text; e.n_bytes = n_bytes; e.rpb = rpb; e.flags = flags; e.d_out = d_out; e.out_cap = out_cap; e.stream = st;
 
     EncInfo *info = e.info.as<EncInfo>();
     uint32_t *tile = e.tile_cnt.as<uint32_t>(), *ls = e.ls.as<uint32_t>(), *E = e.E.as<uint32_t>();
+    uint8_t *lf = e.lf.as<uint8_t>();
     uint32_t *partials = e.partials.as<uint32_t>(), *csize = e.csize.as<uint32_t>();
     BlockPlan *plans = e.plans.as<BlockPlan>();
     uint8_t *arena = e.arena.as<uint8_t>(), *npos = e.npos.as<uint8_t>(), *slots = e.slots.as<uint8_t>();
@@ -712,27 +1266,50 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if (e.n_tiles) {
         PROF(ctx, st, "k_count_nl", hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile));
         launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, 1, e.n_tiles + 1, partials, pmax);
-        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile, ls, e.line_cap));
+        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile, ls, lf, e.line_cap));
     } else {
         HIP_TRY(hipMemsetAsync(tile, 0, 8, st));
         HIP_TRY(hipMemsetAsync(ls, 0, 8, st));
+        HIP_TRY(hipMemsetAsync(lf, 0, 8, st));
     }
     PROF(ctx, st, "k_setup_records", hipLaunchKernelGGL(k_setup_records, dim3(1), dim3(64), 0, st, info, tile, e.n_tiles, ls, e.line_cap, e.rec_cap, e.block_cap, rpb,
                        final_batch, n));
     uint32_t rec_grid = (e.rec_cap + 255) / 256;
     if (rec_grid > 4096) rec_grid = 4096;
-    PROF(ctx, st, "k_record_meta", hipLaunchKernelGGL(k_record_meta, dim3(rec_grid), dim3(256), 0, st, d_text, ls, info, E, estride, final_batch));
+    PROF(ctx, st, "k_record_meta", hipLaunchKernelGGL(k_record_meta, dim3(rec_grid), dim3(256), 0, st, ls, lf, info, E, estride, final_batch));
     if (qual_encoding == FQZ_DETECT_ENCODING) {
         PROF(ctx, st, "k_detect", hipLaunchKernelGGL(k_detect, dim3(grid_for_waves(rpb < e.rec_cap ? rpb : e.rec_cap)), dim3(256), 0, st, d_text, ls, info, rpb));
         hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
     }
     launch_scan(ctx, "scan_records", st, E, &info->n_rec, 0, e.rec_cap, 4, estride, partials, pmax); // seq, qual, hdr, plus
-    PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(64), 0, st, info, E, estride, plans, rpb, e.arena_cap));
-    PROF(ctx, st, "k_split_seq", hipLaunchKernelGGL(k_split_seq, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena));
-    launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
-    PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
-    PROF(ctx, st, "k_split_rest", hipLaunchKernelGGL(k_split_rest, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena, npos));
-    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
+    PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(64), 0, st, info, E, estride, plans, rpb, fused ? (size_t)0xFFFFFFF0ull : e.arena_cap, (uint32_t)main_cap));
+    if (fused) {
+        // chunks of the five main streams are built from the text inside the entropy kernel (LDS only)
+        uint32_t *chunk_rec = e.chunk_rec.as<uint32_t>();
+        PROF(ctx, st, "k_chunk_map", hipLaunchKernelGGL(k_chunk_map, dim3(((uint32_t)main_cap + 255) / 256), dim3(256), 0, st, info, plans, E, estride, chunk_rec));
+        PROF(ctx, st, "k_entropy_fused", hipLaunchKernelGGL(k_entropy_fused, dim3((uint32_t)main_cap), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, chunk_rec,
+                                                          slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
+        launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
+        PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
+        PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, npos));
+        PROF(ctx, st, "k_entropy_npos", hipLaunchKernelGGL(k_entropy, dim3((uint32_t)npos_chunk_cap), dim3(256), 0, st, info, plans, npos, npos, slots, csize, 1, 0,
+                                                         (unsigned long long *)nullptr));
+    } else {
+        // default pipeline: the six pre-entropy streams are materialised in HBM (fqz_debug_get_streams reads them)
+        static const bool old_split = getenv("FQZ_OLD_SPLIT") && atoi(getenv("FQZ_OLD_SPLIT"));
+        if (old_split) {
+            PROF(ctx, st, "k_split_seq", hipLaunchKernelGGL(k_split_seq, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena));
+            launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
+            PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
+            PROF(ctx, st, "k_split_rest", hipLaunchKernelGGL(k_split_rest, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena, npos));
+        } else {
+            PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
+            launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
+            PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
+            PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, npos));
+        }
+        PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize, 0, fqz_dbg_stop(), fqz_dbg_stamps(e)));
+    }
     launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, 1, e.chunk_cap + 1, partials, pmax);
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out));
@@ -784,7 +1361,7 @@ int fqz_enc_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_
 {
     EncState &e = ctx->enc;
     const EncInfo *hi = e.h_info.as<EncInfo>();
-    if (!hi || e.in_flight || block >= hi->n_blocks) return FQZ_E_ARG;
+    if (!hi || e.in_flight || block >= hi->n_blocks || !e.streams_valid) return FQZ_E_ARG;
     BlockPlan p;
     HIP_TRY(hipMemcpy(&p, e.plans.as<BlockPlan>() + block, sizeof p, hipMemcpyDeviceToHost));
     for (int s = 0; s < FQZ_NS; s++) {
@@ -813,6 +1390,7 @@ __global__ void k_single_plan(EncInfo *info, BlockPlan *plans, uint32_t n)
     plans[0] = p;
     info->n_blocks = 1;
     info->n_chunks = chunks;
+    info->n_main = chunks;
 }
 
 __global__ void k_single_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap)
@@ -845,7 +1423,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     uint32_t *csize = e.csize.as<uint32_t>();
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, 0);
     hipLaunchKernelGGL(k_single_plan, dim3(1), dim3(64), 0, st, info, plans, (uint32_t)n);
-    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize, 0, 0, (unsigned long long *)nullptr));
     launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks, 1, chunks + 1, e.partials.as<uint32_t>(), chunks / SCAN_TILE + 2);
     hipLaunchKernelGGL(k_single_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_dst, cap);
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, d_dst));

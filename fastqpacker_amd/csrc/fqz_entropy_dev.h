@@ -372,6 +372,42 @@ __device__ __forceinline__ void load_chunk_and_histogram(EntropyLds &S, const ui
     if (lane == 0 && n_cand) atomicAdd(&hist[cand], n_cand);
 }
 
+// Same histogram for a chunk that is already in S.chunk (fused path: the chunk was assembled in LDS).
+__device__ __forceinline__ void histogram_from_lds(EntropyLds &S, const uint32_t m)
+{
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    uint32_t *hist = lds_hist(S) + wave * 256;
+    uint4 v[4];
+    uint32_t have[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t off = (t + 256 * q) * 16;
+        have[q] = off < m ? (m - off < 16 ? m - off : 16) : 0;
+        v[q] = *(const uint4 *)&S.chunk[(t + 256 * q) * 4];
+    }
+    const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v[0].x & 0xFF)); // wave-uniform candidate byte
+    const uint32_t cand4 = cand * 0x01010101u;
+    uint32_t n_cand = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint32_t valid = have[q] >= 4u * d + 4 ? 0x80808080u : (have[q] > 4u * d ? (0x80808080u >> (8 * (4 * d + 4 - have[q]))) : 0u);
+            uint32_t eq = zero_bytes(w[d] ^ cand4) & valid;
+            n_cand += __popc(eq);
+            uint32_t other = valid & ~eq;
+            while (other) {
+                int bit = __ffs(other) - 1;
+                other &= other - 1;
+                atomicAdd(&hist[(w[d] >> (bit - 7)) & 0xFF], 1u);
+            }
+        }
+    }
+    n_cand = wave_sum(n_cand);
+    if (lane == 0 && n_cand) atomicAdd(&hist[cand], n_cand);
+}
+
 // ---------------------------------------------------------------------------------------------
 // One chunk -> one zstd block.  Preconditions (after a __syncthreads()):
 //   S.chunk holds the m bytes (zero padded to a multiple of 16 + 16), lds_hist(S)[wave*256 + sym]

@@ -25,7 +25,8 @@ struct EncInfo {
     uint32_t error_record;
     uint32_t min_qual;      // min quality byte of block 0 (DetectEncoding)
     uint32_t qual_off;      // 33 or 64
-    uint32_t n_chunks;
+    uint32_t n_chunks;      // all chunks: ids [0, n_main) = seq/qual/headers/plus/lengths, [n_main, n_chunks) = nPos
+    uint32_t n_main;
     uint32_t arena_used;    // bytes of the main arena in use
     uint32_t npos_used;
     unsigned long long error_key; // (record << 8 | check order << 4 | code index), min wins
