@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "lib", "libfqzhip.so")
+_SO = os.environ.get("FQZ_LIB_PATH") or os.path.join(_HERE, "lib", "libfqzhip.so")  # FQZ_LIB_PATH: A/B builds in tools/
 
 ENCODING_PHRED33 = 0
 ENCODING_PHRED64 = 1
@@ -77,7 +77,6 @@ SIGNATURES = {
     "fqz_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "fqz_ctx_destroy": (None, [_vp]),
     "fqz_device_count": (C.c_int, []),
-    "fqz_ctx_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "fqz_write_file_header": (None, [C.POINTER(FileHeader), _u8p]),
     "fqz_read_file_header": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(FileHeader)]),
     "fqz_write_block_header": (C.c_int, [C.POINTER(BlockHeader), C.c_uint8, _u8p]),
@@ -183,12 +182,6 @@ def _ctx_profile_read(self):
     return {k: (ms[i], calls[i]) for i, k in enumerate(keys)}
 
 
-def _ctx_fused_split(self, on=True):
-    """FQZ_OPT_FUSED_SPLIT: build entropy chunks in LDS straight from the text (no pre-entropy streams in HBM)."""
-    check(lib().fqz_ctx_set_option(self._h, 1, 1 if on else 0))
-
-
-Ctx.fused_split = _ctx_fused_split
 Ctx.profile = _ctx_profile
 Ctx.profile_read = _ctx_profile_read
 

@@ -83,18 +83,10 @@ extern "C" int fqz_ctx_create(int device, fqz_ctx **out)
     fqz_ctx *c = new (std::nothrow) fqz_ctx();
     if (!c) return FQZ_E_NOMEM;
     c->device = device;
-    { const char *u = getenv("FQZ_FUSED"); c->enc.unfused = !(u && atoi(u) != 0); }
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fqz_set_hip_error(e, "hipStreamCreate"); }
     *out = c;
     return FQZ_OK;
-}
-
-extern "C" int fqz_ctx_set_option(fqz_ctx *ctx, int option, int value)
-{
-    if (!ctx) return FQZ_E_ARG;
-    if (option == FQZ_OPT_FUSED_SPLIT) { ctx->enc.unfused = value == 0; return FQZ_OK; }
-    return FQZ_E_ARG;
 }
 
 extern "C" void fqz_ctx_destroy(fqz_ctx *c)
@@ -103,7 +95,7 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     EncState &e = c->enc;
-    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.partials, &e.stamps, &e.chunk_rec};
+    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.partials, &e.stamps, &e.lf};
     for (DevBuf *b : eb) b->release();
     e.h_info.release(); e.h_plans.release();
     DecState &d = c->dec;

@@ -79,9 +79,7 @@ struct EncState {
     DevBuf csize;     // u32[chunk_cap+1] -> exclusive prefix
     DevBuf partials;  // scan partial sums
     DevBuf stamps;    // diagnostic s_memtime stamps (FQZ_DBG_STAMPS)
-    DevBuf chunk_rec; // first record of every main chunk (fused pipeline)
-    bool unfused = true;        // materialise the six pre-entropy streams in HBM (default; the fused variant is FQZ_OPT_FUSED_SPLIT)
-    bool streams_valid = false; // the last encode ran unfused: fqz_debug_get_streams can read them
+    bool streams_valid = false; // an encode has run: fqz_debug_get_streams can read its streams
     PinnedBuf h_info; // EncInfo
     PinnedBuf h_plans;
 };

@@ -331,74 +331,15 @@ __global__ void k_plan2(EncInfo *info, const uint32_t *E, uint32_t estride, Bloc
 }
 
 // ===========================================================================
-// K1..K4 the record loop of compressBlockWithBuffers (compress.go:474-520), two kernels:
-//   k_split_seq : 2-bit pack + N count                      (sequence.go:139-184)
-//   k_split_rest: quality delta, headers, plus, lengths, N positions (compress.go:495-519, quality.go:53-103)
-// A wave owns 64 consecutive records: every lane first fetches the metadata of "its" record with
-// coalesced loads (line starts as one uint4, the scanned offsets, the block plan), then the wave walks
-// the 64 records with all lanes on one record, the metadata broadcast through v_readlane (SGPR index).
-// That leaves one dependent global round trip per record (the text itself) instead of four.
+// K1..K4 the record loop of compressBlockWithBuffers (compress.go:474-520):
+//   k_split     : 2-bit pack + N count (sequence.go:139-184), quality delta (quality.go:53-103),
+//                 headers, plus lines, lengths (compress.go:495-519)
+//   k_npos_write: the N positions of the (rare) reads that have any, once their total is scanned
 // ===========================================================================
 #define RL(v, i) __builtin_amdgcn_readlane((int)(v), (i))
 
-__global__ __launch_bounds__(256) void k_split_seq(const uint8_t *text, const uint32_t *ls, EncInfo *info, uint32_t *E, uint32_t estride,
-                                                   const BlockPlan *plans, uint32_t rpb, uint8_t *arena)
-{
-    const uint32_t n_rec = info->n_rec;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
-    const uint32_t *Eseq = E + (size_t)S_SEQ * estride, *Equal = E + (size_t)S_QUAL * estride;
-    uint32_t *Enpos = E + (size_t)S_NPOS * estride;
-    const uint32_t n_groups = (n_rec + 63) >> 6;
-    for (uint32_t g = wave; g < n_groups; g += nwaves) {
-        const uint32_t r = g * 64 + lane;
-        uint32_t m_src = 0, m_len = 0, m_dst = 0;
-        if (r < n_rec) {
-            const BlockPlan *p = &plans[r / rpb];
-            m_src = ls[4 * r + 1];
-            m_len = Equal[r + 1] - Equal[r];
-            m_dst = p->a_off[S_SEQ] + (Eseq[r] - Eseq[p->rec0]);
-        }
-        uint32_t my_nn = 0, my_err = 0;
-        const int cnt = (int)(n_rec - g * 64 < 64 ? n_rec - g * 64 : 64);
-        for (int i = 0; i < cnt; i++) {
-            const uint32_t L = (uint32_t)RL(m_len, i);
-            const uint8_t *src = text + (uint32_t)RL(m_src, i);
-            uint8_t *dst = arena + (uint32_t)RL(m_dst, i);
-            uint32_t nn = 0, beyond = 0;
-            for (uint32_t k = lane; 4 * k < L; k += WAVE) {
-                // the sequence line is followed by "\n+...\n<L quality bytes>": a 4-byte read never leaves the text
-                uint32_t x = load_u32_unaligned(src + 4 * k);
-                uint32_t have = L - 4 * k;
-                uint32_t in_read = 0x80808080u;
-                if (have < 4) { x &= (1u << (8 * have)) - 1; in_read >>= 8 * (4 - have); } // bytes past the read pack as 0
-                uint32_t valid = acgt_mask(x);
-                uint32_t invalid = ~valid & in_read;
-                dst[k] = (uint8_t)pack4(x, valid);
-                if (invalid) {
-                    if (4 * k + 3 < FQZ_MAX_SEQUENCE_LENGTH) nn += __popc(invalid);
-                    else {
-                        for (uint32_t j = 0; j < 4; j++)
-                            if (invalid & (0x80u << (8 * j))) { if (4 * k + j < FQZ_MAX_SEQUENCE_LENGTH) nn++; else beyond = 1; }
-                    }
-                }
-            }
-            // N's are rare: skip the reductions when the whole wave saw none
-            if (__ballot(nn | beyond)) {
-                nn = wave_sum(nn);
-                beyond = wave_sum(beyond);
-                if (lane == (uint32_t)i) { my_nn = nn; my_err = beyond; }
-            }
-        }
-        if (r < n_rec) {
-            if (my_err) report_error(info, r, 4, FQZ_E_LONG_N);  // compress.go:477-488
-            if (my_nn > 65535u) { report_error(info, r, 5, FQZ_E_FIELD_WRAP); my_nn = 0; }
-            Enpos[r] = 2 + 2 * my_nn;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Piece-centric split (default): a wave takes 64 records; their bases, qualities, header and plus payloads are cut into
+// Piece-centric split: a wave takes 64 records; their bases, qualities, header and plus payloads are cut into
 // 16-byte pieces of ONE text line each, and every lane of every round handles one piece: 16 text bytes in (unaligned
 // 128-bit load), 4 packed / 16 delta-coded / 16 copied bytes out.  All lanes are busy whatever the read length and a
 // wave-wide load covers ~1 KiB of text.  The piece -> record map is a binary search over a wave scan of the per-record
@@ -558,93 +499,6 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
     }
 }
 
-__device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
-{
-    for (uint32_t i = lane; i < n; i += WAVE) dst[i] = src[i];
-}
-
-__global__ __launch_bounds__(256) void k_split_rest(const uint8_t *text, const uint32_t *ls, const EncInfo *info, const uint32_t *E,
-                                                    uint32_t estride, const BlockPlan *plans, uint32_t rpb, uint8_t *arena, uint8_t *npos_arena)
-{
-    const uint32_t n_rec = info->n_rec, qoff = info->qual_off;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
-    const uint32_t *Equal = E + (size_t)S_QUAL * estride, *Ehdr = E + (size_t)S_HDR * estride;
-    const uint32_t *Eplus = E + (size_t)S_PLUS * estride, *Enpos = E + (size_t)S_NPOS * estride;
-    const uint32_t n_groups = (n_rec + 63) >> 6;
-    for (uint32_t g = wave; g < n_groups; g += nwaves) {
-        const uint32_t r = g * 64 + lane;
-        // per-lane metadata of record r
-        uint32_t s_hdr = 0, s_seq = 0, s_plus = 0, s_qual = 0, L = 0, H = 0, P = 0, NN = 0;
-        uint32_t d_qual = 0, d_hdr = 0, d_plus = 0, d_npos = 0;
-        if (r < n_rec) {
-            const uint4 l4 = *(const uint4 *)(ls + 4 * (size_t)r); // starts of the record's four lines
-            s_hdr = l4.x + 1; s_seq = l4.y; s_plus = l4.z + 1; s_qual = l4.w;
-            const BlockPlan *p = &plans[r / rpb];
-            const uint32_t r0 = p->rec0;
-            uint32_t eq = Equal[r], eh = Ehdr[r], ep = Eplus[r], en = Enpos[r];
-            L = Equal[r + 1] - eq; H = Ehdr[r + 1] - eh - 2; P = Eplus[r + 1] - ep - 2; NN = (Enpos[r + 1] - en - 2) >> 1;
-            d_qual = p->a_off[S_QUAL] + (eq - Equal[r0]);
-            d_hdr = p->a_off[S_HDR] + (eh - Ehdr[r0]);
-            d_plus = p->a_off[S_PLUS] + (ep - Eplus[r0]);
-            d_npos = p->a_off[S_NPOS] + (en - Enpos[r0]);
-            // ---- length: u32 L (one coalesced store per lane)
-            *(uint32_t *)(arena + p->a_off[S_LEN] + 4 * (r - r0)) = L;
-            // ---- record prefixes: u16 H, u16 P, u16 N count
-            uint8_t *dh = arena + d_hdr, *dp = arena + d_plus, *dn = npos_arena + d_npos;
-            dh[0] = (uint8_t)H; dh[1] = (uint8_t)(H >> 8);
-            dp[0] = (uint8_t)P; dp[1] = (uint8_t)(P >> 8);
-            dn[0] = (uint8_t)NN; dn[1] = (uint8_t)(NN >> 8);
-        }
-        const int cnt = (int)(n_rec - g * 64 < 64 ? n_rec - g * 64 : 64);
-        for (int i = 0; i < cnt; i++) {
-            const uint32_t Li = (uint32_t)RL(L, i);
-            // ---- quality: q'[0] = q[0]-off, q'[k] = q[k]-q[k-1]  (delta restarts per record)
-            {
-                const uint8_t *q = text + (uint32_t)RL(s_qual, i);
-                uint8_t *dst = arena + (uint32_t)RL(d_qual, i);
-                for (uint32_t base = 0; base < Li; base += 4 * WAVE) {
-                    uint32_t k = base + 4 * lane;
-                    uint32_t x = 0, have = 0;
-                    if (k < Li) {
-                        have = Li - k < 4 ? Li - k : 4;
-                        if (have == 4) x = load_u32_unaligned(q + k);
-                        else for (uint32_t j = 0; j < have; j++) x |= (uint32_t)q[k + j] << (8 * j);
-                    }
-                    uint32_t prev = __shfl_up(x >> 24, 1, WAVE);
-                    if (lane == 0) prev = base ? q[base - 1] : qoff;
-                    uint32_t d = sub_bytes(x, (x << 8) | (prev & 0xFF));
-                    if (have == 4) store_u32_unaligned(dst + k, d);
-                    else for (uint32_t j = 0; j < have; j++) dst[k + j] = (uint8_t)(d >> (8 * j));
-                }
-            }
-            // ---- header and plus payload bytes (without '@' / '+')
-            wave_copy_bytes(arena + (uint32_t)RL(d_hdr, i) + 2, text + (uint32_t)RL(s_hdr, i), (uint32_t)RL(H, i), lane);
-            {
-                const uint32_t Pi = (uint32_t)RL(P, i);
-                if (Pi) wave_copy_bytes(arena + (uint32_t)RL(d_plus, i) + 2, text + (uint32_t)RL(s_plus, i), Pi, lane);
-            }
-            // ---- N positions: u16 positions (ascending, < 65536)
-            if (RL(NN, i)) {
-                const uint8_t *sq = text + (uint32_t)RL(s_seq, i);
-                uint8_t *dst = npos_arena + (uint32_t)RL(d_npos, i);
-                uint32_t limit = Li < FQZ_MAX_SEQUENCE_LENGTH ? Li : FQZ_MAX_SEQUENCE_LENGTH, run = 0;
-                for (uint32_t base = 0; base < limit; base += WAVE) {
-                    uint32_t k = base + lane;
-                    bool inv = false;
-                    if (k < limit) inv = (acgt_mask((uint32_t)sq[k] * 0x01010101u) & 0x80u) == 0;
-                    unsigned long long m = __ballot(inv);
-                    if (inv) {
-                        uint32_t w = run + __popcll(m & ((1ull << lane) - 1));
-                        dst[2 + 2 * w] = (uint8_t)k;
-                        dst[3 + 2 * w] = (uint8_t)(k >> 8);
-                    }
-                    run += __popcll(m);
-                }
-            }
-        }
-    }
-}
-
 // ===========================================================================
 // K5/K6 entropy stage: one workgroup per 16 KiB chunk -> one zstd block
 // (replaces zstd.Encoder.EncodeAll, compress.go:523-528; format: RFC 8878)
@@ -677,12 +531,11 @@ __device__ __forceinline__ void locate_chunk(const EncInfo *info, const BlockPla
     *cidx = chunk - p->chunk_base[s];
 }
 
-// chunk source = a pre-entropy stream materialised in HBM (all streams in the unfused pipeline, nPos always)
 __global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const BlockPlan *plans, const uint8_t *arena, const uint8_t *npos_arena,
-                                                 uint8_t *slots, uint32_t *csize, int only_npos, int dbg_stop, unsigned long long *stamps)
+                                                 uint8_t *slots, uint32_t *csize, int dbg_stop, unsigned long long *stamps)
 {
     __shared__ __attribute__((aligned(16))) EntropyLds S;
-    const uint32_t chunk = blockIdx.x + (only_npos ? info->n_main : 0u);
+    const uint32_t chunk = blockIdx.x;
     if (chunk >= info->n_chunks) return;
     const uint32_t t = threadIdx.x;
     if (stamps) { stamps += (size_t)chunk * 16; if (t == 0) stamps[0] = __builtin_amdgcn_s_memtime(); }
@@ -700,315 +553,14 @@ __global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const Bloc
         S.misc[2] = (off + m == p->len[s]);
         S.misc[3] = (uint32_t)s;
     }
-    uint32_t *hist_all = lds_hist(S);
-    for (uint32_t i = t; i < 4 * 256; i += 256) hist_all[i] = 0;
-    if (t < 4) S.chunk[FQZ_CHUNK / 4 + t] = 0;
     __syncthreads();
     const uint32_t m = S.misc[1], last = S.misc[2];
     const uint8_t *src = (S.misc[3] == S_NPOS ? npos_arena : arena) + S.misc[0]; // 16-byte aligned
-
-    // ---- load chunk into LDS + per-wave histograms ---------------------------------
-    load_chunk_and_histogram(S, src, m);
-    __syncthreads();
-    entropy_encode_chunk(S, m, last, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
+    __syncthreads(); // misc[0..3] are reused by the encoder
+    entropy_encode_chunk(S, src, m, last, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
 }
 
-// ===========================================================================
-// Fused path: the chunk is built straight from the FASTQ text into LDS — the six-stream split of
-// compressBlockWithBuffers (compress.go:474-520) never touches HBM.
-// ===========================================================================
-// first record that owns a byte of each main chunk (one thread per chunk; binary search over the scanned offsets)
-__global__ __launch_bounds__(256) void k_chunk_map(const EncInfo *info, const BlockPlan *plans, const uint32_t *E, uint32_t estride, uint32_t *chunk_rec)
-{
-    const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
-    if (chunk >= info->n_main) return;
-    uint32_t b, c;
-    int s;
-    locate_chunk(info, plans, chunk, &b, &s, &c);
-    const BlockPlan *p = &plans[b];
-    if (s == S_LEN) { chunk_rec[chunk] = p->rec0 + c * (FQZ_CHUNK / 4); return; }
-    const uint32_t *Es = E + (size_t)s * estride;
-    const uint32_t base = Es[p->rec0], c0 = c * FQZ_CHUNK;
-    uint32_t lo = p->rec0, hi = p->rec0 + p->nrec; // first r in [lo, hi) whose end lies beyond c0
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (Es[mid + 1] - base > c0) hi = mid; else lo = mid + 1; }
-    chunk_rec[chunk] = lo;
-}
-
-__device__ __forceinline__ void store_lds_bytes(uint8_t *dst, uint32_t v, uint32_t have)
-{
-    if (have == 4) store_u32_unaligned(dst, v); // ds_write_b32 at any byte offset (unaligned DS access is enabled on gfx950)
-    else for (uint32_t j = 0; j < have; j++) dst[j] = (uint8_t)(v >> (8 * j));
-}
-
-__global__ __launch_bounds__(256) void k_entropy_fused(const uint8_t *text, uint32_t n_text, const uint32_t *ls, EncInfo *info, uint32_t *E, uint32_t estride,
-                                                       const BlockPlan *plans, const uint32_t *chunk_rec, uint8_t *slots, uint32_t *csize,
-                                                       int dbg_stop, unsigned long long *stamps)
-{
-    __shared__ __attribute__((aligned(16))) EntropyLds S;
-    const uint32_t chunk = blockIdx.x;
-    if (chunk >= info->n_main) return;
-    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    if (stamps) { stamps += (size_t)chunk * 16; if (t == 0) stamps[0] = __builtin_amdgcn_s_memtime(); }
-    if (t == 0) {
-        uint32_t b, c;
-        int s;
-        locate_chunk(info, plans, chunk, &b, &s, &c);
-        const BlockPlan *p = &plans[b];
-        if (stamps) stamps[15] = (unsigned long long)s;
-        uint32_t off = c * FQZ_CHUNK;
-        uint32_t m = p->len[s] - off < FQZ_CHUNK ? p->len[s] - off : FQZ_CHUNK;
-        S.misc[0] = b;
-        S.misc[1] = m;
-        S.misc[2] = (off + m == p->len[s]);
-        S.misc[3] = (uint32_t)s;
-        S.misc[24] = off;
-        S.misc[25] = chunk_rec[chunk];
-    }
-    uint32_t *hist_all = lds_hist(S);
-    for (uint32_t i = t; i < 4 * 256; i += 256) hist_all[i] = 0;
-    for (uint32_t i = t; i < FQZ_CHUNK / 16 + 1; i += 256) *(uint4 *)&S.chunk[4 * i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    const uint32_t m = S.misc[1], last = S.misc[2], c0 = S.misc[24], r_first = S.misc[25];
-    const int s = (int)S.misc[3];
-    const BlockPlan *p = &plans[S.misc[0]];
-    uint8_t *chunk8 = (uint8_t *)S.chunk;
-    const uint32_t *Equal = E + (size_t)S_QUAL * estride;
-
-    if (s == S_LEN) {
-        // ---- lengths: u32 L per record (compress.go:501)
-        for (uint32_t i = t; 4 * i < m; i += 256) { uint32_t r = r_first + i; S.chunk[i] = Equal[r + 1] - Equal[r]; }
-    } else if (s == S_PLUS && p->len[S_PLUS] == 2 * p->nrec) {
-        // every plus line is bare: the stream is all zero length prefixes, and the chunk buffer is already zero
-    } else {
-        const uint32_t *Es = E + (size_t)s * estride;
-        const uint32_t rec_end = p->rec0 + p->nrec, base = Es[p->rec0];
-        const uint32_t line = s == S_SEQ ? 1 : (s == S_QUAL ? 3 : (s == S_HDR ? 0 : 2));
-        const uint32_t qoff = info->qual_off;
-        // ---- record table of the chunk in LDS (the staging buffer is free until the histogram): for record i of the
-        // chunk, rel[i] = chunk-relative position of its first stream byte (rel[0] <= 0), srco[i] = text offset of its
-        // line (payload start for headers / plus), aux[i] = read length (seq only), pc[i] = number of 16-byte pieces
-        // of the records before it.  rel[cnt] / pc[cnt] are the end sentinels.
-        constexpr uint32_t TCAP = 510;
-        int *rel = (int *)S.out;
-        uint32_t *srco = S.out + (TCAP + 2), *aux = S.out + 2 * (TCAP + 2), *pc = S.out + 3 * (TCAP + 2);
-        const uint32_t cnt = rec_end - r_first < TCAP ? rec_end - r_first : TCAP;
-        uint32_t total_pieces;
-        {
-            uint32_t np[2] = {0, 0};
-#pragma unroll
-            for (int h = 0; h < 2; h++) { // thread t owns records 2t and 2t+1 so that a workgroup scan yields prefix order
-                const uint32_t i = 2 * t + h;
-                if (i <= cnt) {
-                    const uint32_t r = r_first + i;
-                    const uint32_t e0 = Es[r];
-                    rel[i] = (int)(e0 - base - c0);
-                    if (i < cnt) {
-                        srco[i] = ls[4 * r + line] + ((s == S_HDR || s == S_PLUS) ? 1u : 0u);
-                        if (s == S_SEQ) aux[i] = Equal[r + 1] - Equal[r];
-                        np[h] = (Es[r + 1] - e0 + 15) >> 4;
-                    }
-                }
-            }
-            const uint32_t ex = block_excl_scan_256(np[0] + np[1], S.misc + 26, &total_pieces);
-            if (2 * t <= cnt) pc[2 * t] = ex;
-            if (2 * t + 1 <= cnt) pc[2 * t + 1] = ex + np[0];
-        }
-        __syncthreads();
-        const bool table_ok = rel[cnt] >= (int)m; // the table reaches the end of the chunk
-        if (table_ok) {
-            // ---- a lane handles one 16-byte piece of ONE record (pieces never straddle records): dword loads only, all
-            // of a round's loads issued before any is used, results stored at the piece's (unaligned) LDS position
-            constexpr int PB = 2; // pieces per lane per round
-            for (uint32_t p0 = t; p0 < total_pieces; p0 += 256 * PB) {
-                uint32_t pi[PB], pk[PB];
-                bool pv[PB];
-#pragma unroll
-                for (int u = 0; u < PB; u++) {
-                    const uint32_t pp = p0 + 256 * u;
-                    pv[u] = pp < total_pieces;
-                    pi[u] = 0; pk[u] = 0;
-                    if (pv[u]) {
-                        uint32_t lo = 0, hi = cnt; // last record i with pc[i] <= pp (records without pieces share a value)
-                        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (pc[mid] <= pp) lo = mid; else hi = mid; }
-                        pi[u] = lo;
-                        pk[u] = pp - pc[lo];
-                    }
-                }
-                if (s == S_SEQ) {
-                    // ---- bases: piece k = packed bytes 16k..16k+15 = bases 64k..64k+63 (sequence.go:139-184)
-                    uint32_t X[PB][16];
-#pragma unroll
-                    for (int u = 0; u < PB; u++)
-#pragma unroll
-                        for (int bb = 0; bb < 16; bb++) X[u][bb] = 0;
-#pragma unroll
-                    for (int u = 0; u < PB; u++) {
-                        if (!pv[u]) continue;
-                        const uint32_t L = aux[pi[u]];
-                        const uint8_t *src = text + srco[pi[u]] + 64 * pk[u]; // "\n+...\n<quality>" follows: a read never leaves the text
-#pragma unroll
-                        for (int bb = 0; bb < 16; bb++) if (64 * pk[u] + 4 * bb < L) X[u][bb] = load_u32_unaligned(src + 4 * bb);
-                    }
-#pragma unroll
-                    for (int u = 0; u < PB; u++) {
-                        if (!pv[u]) continue;
-                        const uint32_t i = pi[u], L = aux[i], k0 = 16 * pk[u];
-                        const int dst = rel[i] + (int)k0;
-                        const uint32_t plen = (L + 3) >> 2, nb = plen - k0 < 16 ? plen - k0 : 16;
-                        uint32_t w[4] = {0, 0, 0, 0}, nn = 0, beyond = 0;
-#pragma unroll
-                        for (int bb = 0; bb < 16; bb++) {
-                            const uint32_t k = k0 + (uint32_t)bb;
-                            if (k >= plen || dst + bb < 0 || dst + bb >= (int)m) continue; // outside the read or the chunk (a neighbour chunk counts it)
-                            uint32_t x = X[u][bb], have = L - 4 * k, in_read = 0x80808080u;
-                            if (have < 4) { x &= (1u << (8 * have)) - 1; in_read >>= 8 * (4 - have); }
-                            uint32_t vmask = acgt_mask(x);
-                            uint32_t invalid = ~vmask & in_read;
-                            w[bb >> 2] |= pack4(x, vmask) << (8 * (bb & 3));
-                            if (invalid) {
-                                if (4 * k + 3 < FQZ_MAX_SEQUENCE_LENGTH) nn += __popc(invalid);
-                                else
-                                    for (uint32_t z = 0; z < 4; z++)
-                                        if (invalid & (0x80u << (8 * z))) { if (4 * k + z < FQZ_MAX_SEQUENCE_LENGTH) nn++; else beyond = 1; }
-                            }
-                        }
-                        if (beyond) report_error(info, r_first + i, 4, FQZ_E_LONG_N); // compress.go:477-488
-                        if (nn) atomicAdd(&E[(size_t)S_NPOS * estride + r_first + i], 2 * nn);
-                        if (dst >= 0 && dst + 16 <= (int)m && nb == 16) {
-#pragma unroll
-                            for (int q = 0; q < 4; q++) store_u32_unaligned(chunk8 + dst + 4 * q, w[q]);
-                        } else {
-                            for (uint32_t bb = 0; bb < nb; bb++)
-                                if (dst + (int)bb >= 0 && dst + (int)bb < (int)m) chunk8[dst + (int)bb] = (uint8_t)(w[bb >> 2] >> (8 * (bb & 3)));
-                        }
-                    }
-                } else {
-                    // ---- quality (delta, quality.go:53-103) and headers / plus ([u16 H][H bytes], compress.go:514-519)
-                    const int pre = s == S_QUAL ? 0 : 2; // stream bytes that precede the text payload of a record
-                    uint32_t X[PB][4], PV[PB];
-#pragma unroll
-                    for (int u = 0; u < PB; u++) {
-                        PV[u] = qoff;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) X[u][q] = 0;
-                        if (!pv[u]) continue;
-                        const uint32_t so = srco[pi[u]];
-                        const int off = 16 * (int)pk[u] - pre; // payload offset of the piece's first byte (negative inside the prefix)
-                        const int nb = rel[pi[u] + 1] - rel[pi[u]] - 16 * (int)pk[u]; // stream bytes left in the record
-                        if ((int)so + off >= 0 && so + (uint32_t)(off + 16) <= n_text) {
-#pragma unroll
-                            for (int q = 0; q < 4; q++) X[u][q] = load_u32_unaligned(text + so + off + 4 * q);
-                        } else { // first / last bytes of the whole text: byte loads
-                            for (int bb = 0; bb < 16 && bb < nb; bb++)
-                                if ((int)so + off + bb >= 0 && so + (uint32_t)(off + bb) < n_text) X[u][bb >> 2] |= (uint32_t)text[so + off + bb] << (8 * (bb & 3));
-                        }
-                        if (s == S_QUAL && pk[u]) PV[u] = text[so + off - 1];
-                    }
-#pragma unroll
-                    for (int u = 0; u < PB; u++) {
-                        if (!pv[u]) continue;
-                        const uint32_t i = pi[u];
-                        const int rlen = rel[i + 1] - rel[i], k0 = 16 * (int)pk[u];
-                        const int dst = rel[i] + k0, nb = rlen - k0 < 16 ? rlen - k0 : 16;
-                        uint32_t w[4];
-                        if (s == S_QUAL) {
-                            uint32_t prev = PV[u];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) { w[q] = sub_bytes(X[u][q], (X[u][q] << 8) | (prev & 0xFF)); prev = X[u][q] >> 24; }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 4; q++) w[q] = X[u][q];
-                            if (k0 == 0) w[0] = (w[0] & 0xFFFF0000u) | ((uint32_t)(rlen - 2) & 0xFFFFu); // the u16 length prefix
-                        }
-                        if (dst >= 0 && dst + 16 <= (int)m && nb == 16) {
-#pragma unroll
-                            for (int q = 0; q < 4; q++) store_u32_unaligned(chunk8 + dst + 4 * q, w[q]);
-                        } else {
-                            for (int bb = 0; bb < nb; bb++)
-                                if (dst + bb >= 0 && dst + bb < (int)m) chunk8[dst + bb] = (uint8_t)(w[bb >> 2] >> (8 * (bb & 3)));
-                        }
-                    }
-                }
-            }
-        } else {
-            // ---- more records than the table holds (very short reads): a wave walks the records one by one
-            uint32_t *m_src = S.keys;
-            int *m_start = (int *)S.sorted;
-            uint32_t *m_len = S.ctab;
-            for (uint32_t r_batch = r_first;; r_batch += 256) {
-                const uint32_t r = r_batch + t;
-                int valid = 0;
-                if (r < rec_end) {
-                    uint32_t e0 = Es[r] - base;
-                    valid = e0 < c0 + m;
-                    m_start[t] = (int)(e0 - c0);
-                    m_len[t] = s == S_SEQ ? Equal[r + 1] - Equal[r] : Es[r + 1] - Es[r];
-                    m_src[t] = ls[4 * r + line] + ((s == S_HDR || s == S_PLUS) ? 1u : 0u);
-                }
-                const int n_valid = __syncthreads_count(valid);
-                for (int i = (int)wave; i < n_valid; i += 4) {
-                    const int S0 = m_start[i];
-                    const uint32_t len = m_len[i];
-                    const uint8_t *src = text + m_src[i];
-                    if (s == S_QUAL) {
-                        const int j_lo = S0 < 0 ? -S0 : 0, j_hi = (int)len < (int)m - S0 ? (int)len : (int)m - S0;
-                        for (int j = j_lo + 4 * (int)lane; ; j += 4 * WAVE) {
-                            if (!__ballot(j < j_hi)) break;
-                            uint32_t x = 0, have = 0;
-                            if (j < j_hi) {
-                                have = (uint32_t)(j_hi - j < 4 ? j_hi - j : 4);
-                                if (m_src[i] + (uint32_t)j + 4 <= n_text) x = load_u32_unaligned(src + j);
-                                else for (uint32_t k = 0; k < have; k++) x |= (uint32_t)src[j + k] << (8 * k);
-                            }
-                            uint32_t prev = __shfl_up(x >> 24, 1, WAVE);
-                            if (lane == 0) prev = j ? src[j - 1] : qoff;
-                            if (have) store_lds_bytes(chunk8 + S0 + j, sub_bytes(x, (x << 8) | (prev & 0xFF)), have);
-                        }
-                    } else if (s == S_SEQ) {
-                        const int plen = (int)((len + 3) >> 2);
-                        const int k_lo = S0 < 0 ? -S0 : 0, k_hi = plen < (int)m - S0 ? plen : (int)m - S0;
-                        uint32_t nn = 0, beyond = 0;
-                        for (int k = k_lo + (int)lane; k < k_hi; k += WAVE) {
-                            uint32_t x = load_u32_unaligned(src + 4 * k);
-                            uint32_t have = len - 4 * (uint32_t)k, in_read = 0x80808080u;
-                            if (have < 4) { x &= (1u << (8 * have)) - 1; in_read >>= 8 * (4 - have); }
-                            uint32_t vmask = acgt_mask(x);
-                            uint32_t invalid = ~vmask & in_read;
-                            chunk8[S0 + k] = (uint8_t)pack4(x, vmask);
-                            if (invalid) {
-                                if (4 * (uint32_t)k + 3 < FQZ_MAX_SEQUENCE_LENGTH) nn += __popc(invalid);
-                                else
-                                    for (uint32_t q = 0; q < 4; q++)
-                                        if (invalid & (0x80u << (8 * q))) { if (4 * (uint32_t)k + q < FQZ_MAX_SEQUENCE_LENGTH) nn++; else beyond = 1; }
-                            }
-                        }
-                        if (__ballot(nn | beyond)) {
-                            nn = wave_sum(nn);
-                            beyond = wave_sum(beyond);
-                            if (lane == 0) {
-                                const uint32_t rr = r_batch + (uint32_t)i;
-                                if (beyond) report_error(info, rr, 4, FQZ_E_LONG_N);
-                                if (nn) atomicAdd(&E[(size_t)S_NPOS * estride + rr], 2 * nn);
-                            }
-                        }
-                    } else {
-                        const int j_lo = S0 < 0 ? -S0 : 0, j_hi = (int)len < (int)m - S0 ? (int)len : (int)m - S0;
-                        const uint32_t H = len - 2;
-                        for (int j = j_lo + (int)lane; j < j_hi; j += WAVE) chunk8[S0 + j] = j < 2 ? (uint8_t)(H >> (8 * j)) : src[j - 2];
-                    }
-                }
-                __syncthreads();
-                if (n_valid < 256) break;
-            }
-        }
-    }
-    __syncthreads();
-    histogram_from_lds(S, m);
-    __syncthreads();
-    entropy_encode_chunk(S, m, last, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
-}
-
-// nPos stream: u16 count + u16 positions per record (compress.go:495-498) into the nPos arena; a wave owns 64 records
+// N positions: u16 count + ascending u16 positions per record (compress.go:477-488, 507-512)
 __global__ __launch_bounds__(256) void k_npos_write(const uint8_t *text, const uint32_t *ls, EncInfo *info, const uint32_t *E, uint32_t estride,
                                                     const BlockPlan *plans, uint32_t rpb, uint8_t *npos_arena)
 {
@@ -1230,7 +782,6 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     const size_t chunk_cap = main_cap + npos_chunk_cap;
     if (chunk_cap > 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
     e.chunk_cap = (uint32_t)chunk_cap;
-    const bool fused = !e.unfused;
     const uint32_t estride = e.rec_cap + 1;
 
     int rc;
@@ -1240,8 +791,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.lf.ensure(e.line_cap + 8))) return rc;
     if ((rc = e.E.ensure(4ull * 5 * estride))) return rc;
     if ((rc = e.plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
-    if (!fused && (rc = e.arena.ensure(e.arena_cap + 64))) return rc; // only the unfused pipeline materialises these streams
-    if (fused && (rc = e.chunk_rec.ensure(4ull * (main_cap + 1)))) return rc;
+    if ((rc = e.arena.ensure(e.arena_cap + 64))) return rc;
     if ((rc = e.npos.ensure(e.npos_cap + 64))) return rc;
     if ((rc = e.slots.ensure((size_t)e.chunk_cap * FQZ_SLOT))) return rc;
     if ((rc = e.csize.ensure(4ull * (e.chunk_cap + 2)))) return rc;
@@ -1252,7 +802,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
     if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
 
-    e.streams_valid = !fused;
+    e.streams_valid = true;
     e.d_text = d_text; e.n_bytes = n_bytes; e.rpb = rpb; e.flags = flags; e.d_out = d_out; e.out_cap = out_cap; e.stream = st;
 
     EncInfo *info = e.info.as<EncInfo>();
@@ -1282,34 +832,12 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
     }
     launch_scan(ctx, "scan_records", st, E, &info->n_rec, 0, e.rec_cap, 4, estride, partials, pmax); // seq, qual, hdr, plus
-    PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(64), 0, st, info, E, estride, plans, rpb, fused ? (size_t)0xFFFFFFF0ull : e.arena_cap, (uint32_t)main_cap));
-    if (fused) {
-        // chunks of the five main streams are built from the text inside the entropy kernel (LDS only)
-        uint32_t *chunk_rec = e.chunk_rec.as<uint32_t>();
-        PROF(ctx, st, "k_chunk_map", hipLaunchKernelGGL(k_chunk_map, dim3(((uint32_t)main_cap + 255) / 256), dim3(256), 0, st, info, plans, E, estride, chunk_rec));
-        PROF(ctx, st, "k_entropy_fused", hipLaunchKernelGGL(k_entropy_fused, dim3((uint32_t)main_cap), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, chunk_rec,
-                                                          slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
-        launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
-        PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
-        PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, npos));
-        PROF(ctx, st, "k_entropy_npos", hipLaunchKernelGGL(k_entropy, dim3((uint32_t)npos_chunk_cap), dim3(256), 0, st, info, plans, npos, npos, slots, csize, 1, 0,
-                                                         (unsigned long long *)nullptr));
-    } else {
-        // default pipeline: the six pre-entropy streams are materialised in HBM (fqz_debug_get_streams reads them)
-        static const bool old_split = getenv("FQZ_OLD_SPLIT") && atoi(getenv("FQZ_OLD_SPLIT"));
-        if (old_split) {
-            PROF(ctx, st, "k_split_seq", hipLaunchKernelGGL(k_split_seq, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena));
-            launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
-            PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
-            PROF(ctx, st, "k_split_rest", hipLaunchKernelGGL(k_split_rest, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, arena, npos));
-        } else {
-            PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
-            launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
-            PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
-            PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, npos));
-        }
-        PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize, 0, fqz_dbg_stop(), fqz_dbg_stamps(e)));
-    }
+    PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(64), 0, st, info, E, estride, plans, rpb, e.arena_cap, (uint32_t)main_cap));
+    PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
+    launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
+    PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
+    PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, npos));
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, 1, e.chunk_cap + 1, partials, pmax);
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out));
@@ -1423,7 +951,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     uint32_t *csize = e.csize.as<uint32_t>();
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, 0);
     hipLaunchKernelGGL(k_single_plan, dim3(1), dim3(64), 0, st, info, plans, (uint32_t)n);
-    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize, 0, 0, (unsigned long long *)nullptr));
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
     launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks, 1, chunks + 1, e.partials.as<uint32_t>(), chunks / SCAN_TILE + 2);
     hipLaunchKernelGGL(k_single_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_dst, cap);
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, d_dst));

@@ -1,14 +1,19 @@
 // fqz_entropy_dev.h — device side of the entropy stage: one 256-thread workgroup turns a <= 16 KiB
-// chunk that already sits in LDS (with its per-wave histograms) into one zstd block.
+// chunk of a pre-entropy stream into one zstd block.
 //
 // Replaces zstd.Encoder.EncodeAll (internal/compress/compress.go:523-528) with the deterministic
 // "FQZ-H1" construction of DESIGN.md §4; byte-identical to oracle/fqz_entropy.c.
 //
+// The kernel is latency bound (serial chains in the table build), so its throughput is set by how many
+// workgroups a CU holds, i.e. by the LDS footprint.  The chunk therefore lives in REGISTERS: it is staged
+// once through the (not yet used) output buffer to hand every lane the 64 consecutive symbols it will
+// encode, then the same LDS becomes the table-build scratch and finally the output block.  18.6 KiB per
+// workgroup -> 8 workgroups per CU.
+//
 // Work split inside the workgroup:
-//   all 256 lanes : histogram merge, rank sort, leaf depths, weights, canonical codes, bit packing
+//   all 256 lanes : histogram, rank sort, leaf depths, weights, canonical codes, bit packing
 //   lane 0        : the two-queue Huffman merge (n_active-1 dependent steps)
-//   wave 0, scalar: the FSE state chain over the weights (inherently sequential): tables live in
-//                   VGPR lanes and are indexed with v_readlane, state and bit buffer live in SGPRs
+//   all four waves: the FSE compression of the weights (speculative chains, see fse_weights_wg)
 #pragma once
 #include "fqz_device.h"
 
@@ -30,22 +35,27 @@ struct HufScratch {          // aliases the (not yet used) output staging buffer
     uint8_t endmap[2][4][64];// end state of a chunk for every possible start state
 };
 
+#define KEYS_WORD_OFF 1472   // sort keys / sorted keys (2 x 256 words) sit behind HufScratch
+#define TRACE_WORD_OFF 2048
+static_assert(sizeof(HufScratch) <= KEYS_WORD_OFF * 4, "HufScratch overlaps the sort keys");
+static_assert(KEYS_WORD_OFF + 512 <= TRACE_WORD_OFF, "sort keys overlap the FSE trace");
+
 struct EntropyLds {
-    uint32_t chunk[FQZ_CHUNK / 4 + 4];   // the chunk, zero padded
-    uint32_t out[OUT_WORDS];             // HufScratch during the table build, then the zstd block
-    uint32_t keys[256];
-    uint32_t sorted[256];
-    uint32_t ctab[256];                  // code | nbits << 16
+    uint32_t out[OUT_WORDS];             // chunk staging during the load; HufScratch + sort keys + FSE trace during the
+                                         // table build; then the zstd block
+    uint32_t ctab[256];                  // byte histogram during the load, then code | nbits << 16
     uint32_t cc[128];                    // canonical-code scratch
     uint32_t misc[32];
     uint8_t nbits[256];
     uint8_t w[256];
+#ifdef FQZ_LDS_PAD
+    uint32_t pad[FQZ_LDS_PAD]; // occupancy experiments only
+#endif
 };
-// per-wave histograms alias out[] beyond the HufScratch area; dead before out[] is cleared
-#define HIST_WORD_OFF 2048
-__device__ __forceinline__ uint32_t *lds_hist(EntropyLds &S) { return S.out + HIST_WORD_OFF; }
-// FSE state trace [chain 2][chunk 4][step 32][start state 32] (8 KiB) reuses the histogram area once that is dead
-__device__ __forceinline__ uint8_t *lds_trace(EntropyLds &S) { return (uint8_t *)(S.out + HIST_WORD_OFF); }
+__device__ __forceinline__ uint32_t *lds_keys(EntropyLds &S) { return S.out + KEYS_WORD_OFF; }
+__device__ __forceinline__ uint32_t *lds_sorted(EntropyLds &S) { return S.out + KEYS_WORD_OFF + 256; }
+// FSE state trace [chain 2][chunk 4][step 32][start state 32] (8 KiB)
+__device__ __forceinline__ uint8_t *lds_trace(EntropyLds &S) { return (uint8_t *)(S.out + TRACE_WORD_OFF); }
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -324,111 +334,94 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
 }
 
 // ---------------------------------------------------------------------------------------------
-// Chunk load + byte histogram.  src is 16-byte aligned global memory holding m bytes; the chunk lands in
-// S.chunk (zero padded) and the per-wave counts in lds_hist(S)[wave*256 + byte] (zeroed by the caller).
-// Skewed data (quality deltas are ~90 % zeros) would serialise LDS atomics on one bin, so every wave first
-// peels off its dominant byte: the candidate is the first byte the wave sees, matches are counted with
-// SWAR compares in registers and added once per wave; only the other bytes go through LDS atomics.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_chunk_and_histogram(EntropyLds &S, const uint8_t *src, const uint32_t m)
-{
-    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    uint32_t *hist = lds_hist(S) + wave * 256;
-    uint4 v[4];
-    uint32_t have[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) { // all four loads in flight before the first use
-        uint32_t off = (t + 256 * q) * 16;
-        have[q] = off < m ? (m - off < 16 ? m - off : 16) : 0;
-        v[q] = make_uint4(0, 0, 0, 0);
-        if (have[q] == 16) v[q] = *(const uint4 *)(src + off);
-        else if (have[q]) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (uint32_t k = 0; k < have[q]; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
-            v[q] = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-    }
-    const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v[0].x & 0xFF)); // wave-uniform candidate byte
-    const uint32_t cand4 = cand * 0x01010101u;
-    uint32_t n_cand = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        *(uint4 *)&S.chunk[(t + 256 * q) * 4] = v[q];
-        const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            uint32_t valid = have[q] >= 4u * d + 4 ? 0x80808080u : (have[q] > 4u * d ? (0x80808080u >> (8 * (4 * d + 4 - have[q]))) : 0u);
-            uint32_t eq = zero_bytes(w[d] ^ cand4) & valid;
-            n_cand += __popc(eq);
-            uint32_t other = valid & ~eq; // 0x80 per byte that still needs an atomic
-            while (other) {
-                int bit = __ffs(other) - 1; // 7, 15, 23 or 31
-                other &= other - 1;
-                atomicAdd(&hist[(w[d] >> (bit - 7)) & 0xFF], 1u);
-            }
-        }
-    }
-    n_cand = wave_sum(n_cand);
-    if (lane == 0 && n_cand) atomicAdd(&hist[cand], n_cand);
-}
-
-// Same histogram for a chunk that is already in S.chunk (fused path: the chunk was assembled in LDS).
-__device__ __forceinline__ void histogram_from_lds(EntropyLds &S, const uint32_t m)
-{
-    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    uint32_t *hist = lds_hist(S) + wave * 256;
-    uint4 v[4];
-    uint32_t have[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        uint32_t off = (t + 256 * q) * 16;
-        have[q] = off < m ? (m - off < 16 ? m - off : 16) : 0;
-        v[q] = *(const uint4 *)&S.chunk[(t + 256 * q) * 4];
-    }
-    const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v[0].x & 0xFF)); // wave-uniform candidate byte
-    const uint32_t cand4 = cand * 0x01010101u;
-    uint32_t n_cand = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            uint32_t valid = have[q] >= 4u * d + 4 ? 0x80808080u : (have[q] > 4u * d ? (0x80808080u >> (8 * (4 * d + 4 - have[q]))) : 0u);
-            uint32_t eq = zero_bytes(w[d] ^ cand4) & valid;
-            n_cand += __popc(eq);
-            uint32_t other = valid & ~eq;
-            while (other) {
-                int bit = __ffs(other) - 1;
-                other &= other - 1;
-                atomicAdd(&hist[(w[d] >> (bit - 7)) & 0xFF], 1u);
-            }
-        }
-    }
-    n_cand = wave_sum(n_cand);
-    if (lane == 0 && n_cand) atomicAdd(&hist[cand], n_cand);
-}
-
-// ---------------------------------------------------------------------------------------------
-// One chunk -> one zstd block.  Preconditions (after a __syncthreads()):
-//   S.chunk holds the m bytes (zero padded to a multiple of 16 + 16), lds_hist(S)[wave*256 + sym]
-//   holds the per-wave byte counts.  All 256 threads call this; they return together.
+// One chunk -> one zstd block.  src is 16-byte aligned global memory holding the m chunk bytes.
+// All 256 threads call this; they return together.
+//
+// Symbol ownership (fixed by the format: 4 Huffman streams of ceil(m/4) bytes when m >= 256, else 1): wave w
+// encodes stream w, lane l the `per` consecutive symbols [l*per, (l+1)*per) of it, per <= 64, kept in sym[16].
 // ---------------------------------------------------------------------------------------------
 // dbg_stop > 0 (FQZ_DBG_STOP, timing experiments only): leave after that phase with a dummy 4-byte block
 // stamps != nullptr (FQZ_DBG_STAMPS, diagnostic runs only): lane 0 records s_memtime at every phase boundary
 #define DBG_STOP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime(); \
                          if (dbg_stop == (k)) { if (threadIdx.x == 0) *csize_out = 4; return; } } while (0)
-__device__ void entropy_encode_chunk(EntropyLds &S, const uint32_t m, const uint32_t last, uint8_t *slot, uint32_t *csize_out, const int dbg_stop = 0,
-                                     unsigned long long *stamps = nullptr)
+__device__ __forceinline__ uint32_t lds_load_u32_unaligned(const uint8_t *p)
 {
-    DBG_STOP(1);
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+__device__ void entropy_encode_chunk(EntropyLds &S, const uint8_t *src, const uint32_t m, const uint32_t last, uint8_t *slot, uint32_t *csize_out,
+                                     const int dbg_stop = 0, unsigned long long *stamps = nullptr)
+{
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    uint32_t *hist = lds_hist(S);
+    // ---- stage the chunk in LDS with coalesced 128-bit loads (bytes at or beyond m read as 0)
+    {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { // all four loads in flight before the first use
+            const uint32_t off = (t + 256 * q) * 16;
+            const uint32_t have = off < m ? (m - off < 16 ? m - off : 16) : 0;
+            v[q] = make_uint4(0, 0, 0, 0);
+            if (have == 16) v[q] = *(const uint4 *)(src + off);
+            else if (have) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; k < have; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
+                v[q] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        S.ctab[t] = 0;
+        if (t < OUT_WORDS - FQZ_CHUNK / 4) S.out[FQZ_CHUNK / 4 + t] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) *(uint4 *)&S.out[(t + 256 * q) * 4] = v[q];
+    }
+    __syncthreads();
+    // ---- my symbols -> registers; byte histogram.  Skewed data (quality deltas are ~90 % zeros) would serialise LDS
+    //      atomics on one bin, so every wave first peels off its dominant byte: the candidate is the first byte the wave
+    //      sees, matches are counted with SWAR compares in registers and added once per wave.
+    const uint32_t nstreams = m >= 256 ? 4 : 1;
+    const uint32_t seg = nstreams == 4 ? (m + 3) / 4 : m;
+    const uint32_t seg_base = wave * seg;
+    uint32_t seg_len = 0;
+    if (wave < nstreams) seg_len = (wave == nstreams - 1) ? m - seg_base : seg;
+    const uint32_t per = ((seg_len + 63) / 64 + 3) & ~3u; // symbols per lane, a multiple of 4, <= 64
+    uint32_t sym_a = lane * per, sym_b = sym_a + per;
+    if (sym_a > seg_len) sym_a = seg_len;
+    if (sym_b > seg_len) sym_b = seg_len;
+    const uint32_t cnt = sym_b - sym_a;
+    uint32_t sym[16];
+    {
+        const uint8_t *mine = (const uint8_t *)S.out + seg_base + sym_a;
+#pragma unroll
+        for (int d = 0; d < 16; d++) sym[d] = 4u * d < cnt ? lds_load_u32_unaligned(mine + 4 * d) : 0u;
+        const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sym[0] & 0xFF)); // wave-uniform candidate byte
+        const uint32_t cand4 = cand * 0x01010101u;
+        uint32_t n_cand = 0;
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            const uint32_t valid = cnt >= 4u * d + 4 ? 0x80808080u : (cnt > 4u * d ? (0x80808080u >> (8 * (4 * d + 4 - cnt))) : 0u);
+            const uint32_t eq = zero_bytes(sym[d] ^ cand4) & valid;
+            n_cand += __popc(eq);
+            uint32_t other = valid & ~eq; // 0x80 per byte that still needs an atomic
+            while (other) {
+                int bit = __ffs(other) - 1; // 7, 15, 23 or 31
+                other &= other - 1;
+                atomicAdd(&S.ctab[(sym[d] >> (bit - 7)) & 0xFF], 1u);
+            }
+        }
+        n_cand = wave_sum(n_cand);
+        if (lane == 0 && n_cand) atomicAdd(&S.ctab[cand], n_cand);
+    }
+    __syncthreads(); // the staging copy is dead, the histogram complete
+    DBG_STOP(1);
+    uint32_t *const keys = lds_keys(S), *const sorted = lds_sorted(S);
     // S.misc: 4 n_active, 5 mode (0 raw, 1 rle, 2 huffman), 6 tree size, 7 max bits, 8..11 per-wave scratch / stream bits,
     //         12 total bytes, 13 max count, 14 tree offset, 16..19 per-wave scratch, 20 max depth, 21 nw
     // ---- merge histograms, classify -------------------------------------------------
     {
-        uint32_t c = hist[t] + hist[256 + t] + hist[512 + t] + hist[768 + t];
-        S.keys[t] = c ? ((c << 8) | t) : 0u;
+        uint32_t c = S.ctab[t];
+        keys[t] = c ? ((c << 8) | t) : 0u;
+        if (c) S.misc[30] = t; // the byte of an RLE block
         unsigned long long act = __ballot(c != 0);
         uint32_t sq = wave_sum(c * c); // c <= 16384, the sum of squares <= 2^28
         if (lane == 0) { S.misc[8 + wave] = (uint32_t)__popcll(act); S.misc[16 + wave] = sq; }
@@ -451,23 +444,23 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint32_t m, const uint
         // ---- sort the active symbols by (count, symbol): compact the non-zero keys, then every active key
         //      counts the smaller ones (keys are distinct)
         {
-            uint32_t my = S.keys[t];
+            uint32_t my = keys[t];
             unsigned long long bm = __ballot(my != 0);
             if (lane == 0) S.misc[16 + wave] = (uint32_t)__popcll(bm);
             __syncthreads();
             uint32_t base = 0;
             for (uint32_t w2 = 0; w2 < wave; w2++) base += S.misc[16 + w2];
-            if (my) S.sorted[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1))] = my; // compacted, unsorted
+            if (my) sorted[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1))] = my; // compacted, unsorted
             __syncthreads();
-            uint32_t mine = t < n_active ? S.sorted[t] : 0, rank = 0;
-            for (uint32_t j = 0; j < n_active; j++) rank += S.sorted[j] < mine;
+            uint32_t mine = t < n_active ? sorted[t] : 0, rank = 0;
+            for (uint32_t j = 0; j < n_active; j++) rank += sorted[j] < mine;
             __syncthreads();
-            if (t < n_active) S.sorted[256 - n_active + rank] = mine;
+            if (t < n_active) sorted[256 - n_active + rank] = mine;
         }
         __syncthreads();
         DBG_STOP(3);
         const uint32_t n = n_active;
-        const uint32_t *key = S.sorted + (256 - n);
+        const uint32_t *key = sorted + (256 - n);
         if (t < n) sc->cnt[t] = key[t] >> 8;
         __syncthreads();
         // ---- two-queue Huffman merge, leaf preferred on ties (one lane)
@@ -605,20 +598,16 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint32_t m, const uint
 
         DBG_STOP(6);
         // ---- pass 1: bits per lane, per stream (wave w encodes stream w)
-        const uint32_t nstreams = m >= 256 ? 4 : 1;
-        const uint32_t seg = nstreams == 4 ? (m + 3) / 4 : m;
-        const uint32_t seg_base = wave * seg;
-        uint32_t seg_len = 0;
-        if (wave < nstreams) seg_len = (wave == nstreams - 1) ? m - seg_base : seg;
-        // symbols per lane: multiple of 4 with an odd dword count -> conflict-free LDS byte reads
-        uint32_t per = ((seg_len + 63) / 64 + 3) & ~3u;
-        if (((per >> 2) & 1) == 0) per += 4;
-        uint32_t a = lane * per, b = a + per;
-        if (a > seg_len) a = seg_len;
-        if (b > seg_len) b = seg_len;
-        const uint8_t *cb = (const uint8_t *)S.chunk + seg_base;
         uint32_t my_bits = 0;
-        for (uint32_t j = a; j < b; j++) my_bits += S.ctab[cb[j]] >> 16;
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            if (4u * d + 4 <= cnt) {
+                my_bits += (S.ctab[sym[d] & 0xFF] >> 16) + (S.ctab[(sym[d] >> 8) & 0xFF] >> 16) + (S.ctab[(sym[d] >> 16) & 0xFF] >> 16) +
+                           (S.ctab[sym[d] >> 24] >> 16);
+            } else if (4u * d < cnt) {
+                for (uint32_t z = 0; z < cnt - 4u * d; z++) my_bits += S.ctab[(sym[d] >> (8 * z)) & 0xFF] >> 16;
+            }
+        }
         uint32_t incl = wave_incl_scan(my_bits);
         uint32_t tot_bits = __shfl(incl, 63, WAVE);
         uint32_t bit_off = tot_bits - incl; // bits of all higher lanes = symbols written before mine
@@ -672,30 +661,28 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint32_t m, const uint
                 uint32_t word = P0 >> 5;
                 uint32_t fill = P0 & 31;
                 unsigned long long acc = 0;
-                uint32_t j = b;
                 // two symbols per step (<= 22 new bits on top of < 32 pending fit the 64-bit accumulator)
-                for (; j >= a + 2; j -= 2) {
-                    uint32_t e1 = S.ctab[cb[j - 1]], e2 = S.ctab[cb[j - 2]];
-                    acc |= (unsigned long long)(e1 & 0xFFFF) << fill;
-                    fill += e1 >> 16;
-                    acc |= (unsigned long long)(e2 & 0xFFFF) << fill;
-                    fill += e2 >> 16;
-                    atomicOr(&S.out[word], (uint32_t)acc);
-                    uint32_t adv = fill >> 5;            // 0 or 1 whole words completed
-                    acc >>= (adv << 5);
-                    word += adv;
-                    fill &= 31;
+#define PUT2(s1, s2) do { uint32_t e1 = S.ctab[(s1)], e2 = S.ctab[(s2)];                         \
+                          acc |= (unsigned long long)(e1 & 0xFFFF) << fill; fill += e1 >> 16;  \
+                          acc |= (unsigned long long)(e2 & 0xFFFF) << fill; fill += e2 >> 16;  \
+                          atomicOr(&S.out[word], (uint32_t)acc);                               \
+                          uint32_t adv = fill >> 5; /* 0 or 1 whole words completed */         \
+                          acc >>= (adv << 5); word += adv; fill &= 31; } while (0)
+#define PUT1(s1) do { uint32_t e1 = S.ctab[(s1)];                                                \
+                      acc |= (unsigned long long)(e1 & 0xFFFF) << fill; fill += e1 >> 16;      \
+                      atomicOr(&S.out[word], (uint32_t)acc);                                   \
+                      uint32_t adv = fill >> 5; acc >>= (adv << 5); word += adv; fill &= 31; } while (0)
+#pragma unroll
+                for (int d = 15; d >= 0; d--) {
+                    if (4u * d + 4 <= cnt) {
+                        PUT2(sym[d] >> 24, (sym[d] >> 16) & 0xFF);
+                        PUT2((sym[d] >> 8) & 0xFF, sym[d] & 0xFF);
+                    } else if (4u * d < cnt) {
+                        for (int z = (int)(cnt - 4u * d) - 1; z >= 0; z--) PUT1((sym[d] >> (8 * z)) & 0xFF);
+                    }
                 }
-                if (j > a) {
-                    uint32_t e = S.ctab[cb[j - 1]];
-                    acc |= (unsigned long long)(e & 0xFFFF) << fill;
-                    fill += e >> 16;
-                    atomicOr(&S.out[word], (uint32_t)acc);
-                    uint32_t adv = fill >> 5;
-                    acc >>= (adv << 5);
-                    word += adv;
-                    fill &= 31;
-                }
+#undef PUT2
+#undef PUT1
                 if (lane == 0) { acc |= 1ull << fill; fill += 1; } // end mark above the first symbol's code
                 if (fill) atomicOr(&S.out[word], (uint32_t)acc);
                 if (fill > 32) atomicOr(&S.out[word + 1], (uint32_t)(acc >> 32));
@@ -713,21 +700,20 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint32_t m, const uint
     if (mode == 1) { // RLE block: 3-byte header + the byte
         if (t == 0) {
             uint32_t bh = (last & 1) | (1u << 1) | (m << 3);
-            uint32_t b0 = ((const uint8_t *)S.chunk)[0];
-            *(uint32_t *)slot = (bh & 0xFFFFFF) | (b0 << 24);
+            *(uint32_t *)slot = (bh & 0xFFFFFF) | (S.misc[30] << 24);
             *csize_out = 4;
         }
         return;
     }
-    // raw block: 3-byte header + m bytes, composed dword-wise from the LDS copy
+    // raw block: 3-byte header + the m bytes, copied from global memory (L2-hot) with 128-bit accesses
     {
-        uint32_t bh = (last & 1) | (0u << 1) | (m << 3);
-        uint32_t total = 3 + m;
-        uint32_t *slot32 = (uint32_t *)slot;
-        for (uint32_t i = t; i < (total + 3) / 4; i += 256) {
-            uint32_t lo = i ? S.chunk[i - 1] : (bh << 8), hi = S.chunk[i];
-            slot32[i] = __builtin_amdgcn_alignbyte(hi, lo, 1); // out bytes 4i..4i+3 = header/chunk bytes 4i-3..4i
+        const uint32_t bh = (last & 1) | (0u << 1) | (m << 3);
+        if (t == 0) { slot[0] = (uint8_t)bh; slot[1] = (uint8_t)(bh >> 8); slot[2] = (uint8_t)(bh >> 16); }
+        for (uint32_t off = t * 16; off < m; off += 256 * 16) {
+            if (off + 16 <= m) store_u128_unaligned(slot + 3 + off, *(const uint4 *)(src + off));
+            else
+                for (uint32_t k = off; k < m; k++) slot[3 + k] = src[k];
         }
-        if (t == 0) *csize_out = total;
+        if (t == 0) *csize_out = 3 + m;
     }
 }

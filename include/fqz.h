@@ -86,12 +86,6 @@ typedef struct fqz_ctx fqz_ctx;
 int fqz_ctx_create(int device, fqz_ctx **out);
 void fqz_ctx_destroy(fqz_ctx *ctx);
 int fqz_device_count(void);
-/* FQZ_OPT_FUSED_SPLIT (0 = off, default): build every 16 KiB entropy chunk in LDS straight from the FASTQ text
- * instead of materialising the six pre-entropy streams in HBM first.  Saves the stream round trip through HBM
- * but runs the gather inside the LDS-occupancy-bound entropy kernel; measured slower on MI355X, so
- * it is an option, not the default.  Output bytes are identical either way; fqz_debug_get_streams needs it off. */
-#define FQZ_OPT_FUSED_SPLIT 1
-int fqz_ctx_set_option(fqz_ctx *ctx, int option, int value);
 
 /* ---- fqformat: container framing (host side, byte-exact) ---------------- */
 typedef struct { /* fqformat.FileHeader container.go:28-32 */
@@ -175,7 +169,7 @@ int fqz_decode_batch_launch(fqz_ctx *ctx, const uint8_t *d_blocks, size_t n_byte
 int fqz_decode_batch_finish(fqz_ctx *ctx, fqz_batch_result *res);
 
 /* Test hook: the six pre-entropy streams of the last
- * fqz_encode_* call's block `block`, copied to host memory (not available after a FQZ_OPT_FUSED_SPLIT encode).  stream_len[k] is
+ * fqz_encode_* call's block `block`, copied to host memory.  stream_len[k] is
  * in/out (capacity in, size out); streams[k] may be NULL to query sizes. */
 int fqz_debug_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_t stream_len[6]);
 

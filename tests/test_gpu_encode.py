@@ -51,14 +51,6 @@ def test_streams_and_block_match_oracle(fq, sample_fq, name):
     block, nrec = fq.compress.encode_block(text, enc)
     assert nrec == n
     got_streams = fq.compress.get_streams(0)
-    # FQZ_OPT_FUSED_SPLIT: chunks are built in LDS straight from the text; same bytes out
-    ctx = fq._lib.default_ctx()
-    ctx.fused_split(True)
-    try:
-        block_fused, _ = fq.compress.encode_block(text, enc)
-    finally:
-        ctx.fused_split(False)
-    assert block_fused == block
     for k, nm in enumerate(O.STREAM_NAMES):
         assert got_streams[k] == want_streams[k], _dump_diff(nm, got_streams[k], want_streams[k])
     # block = 36-byte header + payloads; compare with the oracle's compress() minus the 10-byte file header
@@ -109,19 +101,6 @@ def test_multi_block_batch_matches_oracle(fq):
     body = out[: res.out_len].cpu().numpy().tobytes()
     want = O.compress(text, batch_records=128)
     assert body == want[10:]
-    # the fused-split option yields the same bytes, also for the long-N error path below
-    ctx = fq._lib.default_ctx()
-    ctx.fused_split(True)
-    try:
-        res2, _, _ = fq.compress.encode_batch_dev(t.data_ptr(), t.numel(), out.data_ptr(), out.numel(), records_per_block=128,
-                                                  final=True, max_blocks=64)
-        assert out[: res2.out_len].cpu().numpy().tobytes() == body
-        seq = bytearray(b"ACGT" * 17500)
-        seq[66000] = ord("N")
-        with pytest.raises(fq.FqzError, match="ambiguous bases beyond position"):
-            fq.compress.encode_block(b"@SEQ_LONG\n" + bytes(seq) + b"\n+\n" + b"I" * 70000 + b"\n")
-    finally:
-        ctx.fused_split(False)
     assert offs[0] == 0 and offs[1] == lens[0]
     # not final: only whole blocks are consumed
     res2 = fq.compress.encode_batch_dev(t.data_ptr(), t.numel(), out.data_ptr(), out.numel(), records_per_block=300, final=False)
