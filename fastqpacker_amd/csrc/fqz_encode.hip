@@ -138,36 +138,38 @@ __global__ __launch_bounds__(256) void k_line_starts(const uint8_t *text, uint32
                                                      uint32_t line_cap)
 {
     __shared__ uint32_t sh[4];
-    __shared__ __attribute__((aligned(16))) uint8_t tile[16 + FQZ_TILE + 16]; // the tile's text with one neighbour byte either side
+    __shared__ uint16_t edge[258]; // [t + 1] = first byte | last byte << 8 of thread t; [0] / [257] = the tile's neighbours
     const uint32_t t = threadIdx.x;
     uint32_t off = blockIdx.x * FQZ_TILE + t * 16;
     uint4 v = load_text16(text, off, n);
-    *(uint4 *)&tile[16 + 16 * t] = v;
-    if (t == 0) tile[15] = off ? text[off - 1] : 0;
-    if (t == 255) tile[16 + FQZ_TILE] = off + 16 < n ? text[off + 16] : 0;
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    edge[t + 1] = (uint16_t)((w[0] & 0xFF) | ((w[3] >> 24) << 8));
+    if (t == 0) edge[0] = (uint16_t)(off ? (uint32_t)text[off - 1] << 8 : 0);
+    if (t == 255) edge[257] = (uint16_t)(off + 16 < n ? text[off + 16] : 0);
     uint32_t m[4], c = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { m[k] = zero_bytes(w[k] ^ 0x0A0A0A0Au); c += __popc(m[k]); }
     uint32_t tot;
-    uint32_t idx = tile_off[blockIdx.x] + block_excl_scan_256(c, sh, &tot); // (its barriers also publish tile[])
+    uint32_t idx = tile_off[blockIdx.x] + block_excl_scan_256(c, sh, &tot); // (its barriers also publish edge[])
     if (blockIdx.x == 0 && t == 0) {
         ls[0] = 0;
         lf[0] = (uint8_t)(n ? (((w[0] & 0xFF) == '@' ? 1 : (w[0] & 0xFF) == '+' ? 2 : 0) << 1) : 0);
     }
     if (c) {
-        const uint8_t *mine = tile + 16 + 16 * t;
+        const uint32_t prev_b = edge[t] >> 8, next_b = edge[t + 2] & 0xFF;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             uint32_t mk = m[k];
             while (mk) {
-                int bit = __ffs(mk) - 1; // 7, 15, 23, 31
+                const int bit = __ffs(mk) - 1; // 7, 15, 23, 31
                 mk &= mk - 1;
-                const int q = 4 * k + (bit >> 3);
+                const uint32_t b = (uint32_t)bit >> 3;
+                // the bytes either side of the newline, from registers
+                const uint32_t before = b ? (w[k] >> (8 * b - 8)) & 0xFF : (k ? w[k ? k - 1 : 0] >> 24 : prev_b);
+                const uint32_t after = b < 3 ? (w[k] >> (8 * b + 8)) & 0xFF : (k < 3 ? w[k < 3 ? k + 1 : 3] & 0xFF : next_b);
                 idx++;
                 if (idx <= line_cap) {
-                    const uint32_t before = mine[q - 1], after = mine[q + 1];
-                    ls[idx] = off + q + 1; // line idx starts after newline idx
+                    ls[idx] = off + 4 * k + b + 1; // line idx starts after newline idx
                     lf[idx] = (uint8_t)((before == '\r' ? 1 : 0) | (after == '@' ? 2 : after == '+' ? 4 : 0));
                 }
             }
@@ -266,68 +268,115 @@ __global__ void k_finish_detect(EncInfo *info)
     info->qual_off = (mn != 255 && mn >= 64) ? 64 : 33;
 }
 
-// arena layout of the streams whose sizes are known after the first scans
-__global__ void k_plan1(EncInfo *info, const uint32_t *E, uint32_t estride, BlockPlan *plans, uint32_t rpb, size_t arena_cap, uint32_t main_cap)
+// arena layout of the streams whose sizes are known after the first scans: one thread per block, offsets and
+// chunk ids by a workgroup scan (launch with one 256-thread workgroup)
+__global__ __launch_bounds__(256) void k_plan1(EncInfo *info, const uint32_t *E, uint32_t estride, BlockPlan *plans, uint32_t rpb, size_t arena_cap,
+                                               uint32_t main_cap)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    if (info->error_key != ~0ull && info->status == 0) {
-        info->status = -(int32_t)(info->error_key & 31);
-        info->error_record = (uint32_t)(info->error_key >> 8);
-    }
-    uint32_t n_rec = info->n_rec, n_blocks = info->n_blocks;
-    if (info->status) { info->n_blocks = 0; info->n_rec = 0; return; }
-    unsigned long long a = 0;
-    uint32_t chunks = 0;
-    const int order[5] = {S_SEQ, S_QUAL, S_HDR, S_PLUS, S_LEN};
-    for (uint32_t b = 0; b < n_blocks; b++) {
-        BlockPlan *p = &plans[b];
-        uint32_t r0 = b * rpb, r1 = r0 + rpb < n_rec ? r0 + rpb : n_rec;
-        p->rec0 = r0;
-        p->nrec = r1 - r0;
-        for (int q = 0; q < 5; q++) {
-            int s = order[q];
-            uint32_t len = s == S_LEN ? 4 * (r1 - r0) : E[(size_t)s * estride + r1] - E[(size_t)s * estride + r0];
-            p->len[s] = len;
-            p->a_off[s] = (uint32_t)a;
-            a += (len + 15) & ~15u;
-            info->stream_raw[s] += len;
-            p->chunk_base[s] = chunks; // main chunk ids: block by block, in this stream order
-            chunks += (len + FQZ_CHUNK - 1) / FQZ_CHUNK;
+    __shared__ uint32_t sh[8], s_stop;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) {
+        if (info->error_key != ~0ull && info->status == 0) {
+            info->status = -(int32_t)(info->error_key & 31);
+            info->error_record = (uint32_t)(info->error_key >> 8);
         }
-        p->orig_seq = E[(size_t)S_QUAL * estride + r1] - E[(size_t)S_QUAL * estride + r0];
+        s_stop = info->status != 0;
+        if (s_stop) { info->n_blocks = 0; info->n_rec = 0; }
     }
-    if (a > arena_cap || a > 0xFFFFFFF0ull || chunks > main_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; info->n_rec = 0; return; }
-    info->arena_used = (uint32_t)a;
-    info->n_main = chunks;
-    info->n_chunks = chunks;
+    __syncthreads();
+    if (s_stop) return;
+    const uint32_t n_rec = info->n_rec, n_blocks = info->n_blocks;
+    const int order[5] = {S_SEQ, S_QUAL, S_HDR, S_PLUS, S_LEN};
+    uint32_t carry_a16 = 0, carry_ch = 0; // arena offset in 16-byte units, chunk id
+    bool overflow = false;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 256) {
+        const uint32_t b = b0 + t;
+        uint32_t len[5] = {0, 0, 0, 0, 0}, a16 = 0, ch = 0, r0 = 0, r1 = 0;
+        if (b < n_blocks) {
+            r0 = b * rpb;
+            r1 = r0 + rpb < n_rec ? r0 + rpb : n_rec;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const int s = order[q];
+                len[q] = s == S_LEN ? 4 * (r1 - r0) : E[(size_t)s * estride + r1] - E[(size_t)s * estride + r0];
+                a16 += (len[q] + 15) >> 4;
+                ch += (len[q] + FQZ_CHUNK - 1) / FQZ_CHUNK;
+            }
+        }
+        uint32_t tot_a, tot_c;
+        uint32_t ex_a = carry_a16 + block_excl_scan_256(a16, sh, &tot_a);
+        uint32_t ex_c = carry_ch + block_excl_scan_256(ch, sh + 4, &tot_c);
+        if (b < n_blocks) {
+            BlockPlan *p = &plans[b];
+            p->rec0 = r0;
+            p->nrec = r1 - r0;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const int s = order[q];
+                p->len[s] = len[q];
+                p->a_off[s] = ex_a << 4;
+                ex_a += (len[q] + 15) >> 4;
+                p->chunk_base[s] = ex_c; // main chunk ids: block by block, in this stream order
+                ex_c += (len[q] + FQZ_CHUNK - 1) / FQZ_CHUNK;
+                atomicAdd(&info->stream_raw[s], (unsigned long long)len[q]);
+            }
+            p->orig_seq = len[1];
+        }
+        if ((unsigned long long)carry_a16 + tot_a > 0x0FFFFFFFull) overflow = true;
+        carry_a16 += tot_a;
+        carry_ch += tot_c;
+    }
+    if (t == 0) {
+        const unsigned long long a = (unsigned long long)carry_a16 << 4;
+        if (overflow || a > arena_cap || a > 0xFFFFFFF0ull || carry_ch > main_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; info->n_rec = 0; return; }
+        info->arena_used = (uint32_t)a;
+        info->n_main = carry_ch;
+        info->n_chunks = carry_ch;
+    }
 }
 
-// nPos arena + chunk table once the N counts are scanned
-__global__ void k_plan2(EncInfo *info, const uint32_t *E, uint32_t estride, BlockPlan *plans, size_t npos_cap, uint32_t chunk_cap)
+// nPos arena + chunk table once the N counts are scanned (one 256-thread workgroup)
+__global__ __launch_bounds__(256) void k_plan2(EncInfo *info, const uint32_t *E, uint32_t estride, BlockPlan *plans, size_t npos_cap, uint32_t chunk_cap)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    if (info->error_key != ~0ull && info->status == 0) {
+    __shared__ uint32_t sh[8];
+    const uint32_t t = threadIdx.x;
+    if (t == 0 && info->error_key != ~0ull && info->status == 0) {
         info->status = -(int32_t)(info->error_key & 31);
         info->error_record = (uint32_t)(info->error_key >> 8);
         info->n_blocks = 0;
     }
-    uint32_t n_blocks = info->n_blocks;
-    unsigned long long a = 0;
-    uint32_t chunks = info->n_main;
-    for (uint32_t b = 0; b < n_blocks; b++) {
-        BlockPlan *p = &plans[b];
-        uint32_t r0 = p->rec0, r1 = r0 + p->nrec;
-        uint32_t len = E[(size_t)S_NPOS * estride + r1] - E[(size_t)S_NPOS * estride + r0];
-        p->len[S_NPOS] = len;
-        p->a_off[S_NPOS] = (uint32_t)a;
-        a += (len + 15) & ~15u;
-        info->stream_raw[S_NPOS] += len;
-        p->chunk_base[S_NPOS] = chunks; // nPos chunk ids follow all main chunks
-        chunks += (len + FQZ_CHUNK - 1) / FQZ_CHUNK;
+    __syncthreads();
+    const uint32_t n_blocks = info->n_blocks;
+    uint32_t carry_a16 = 0, carry_ch = info->n_main;
+    bool overflow = false;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 256) {
+        const uint32_t b = b0 + t;
+        uint32_t len = 0;
+        if (b < n_blocks) {
+            const uint32_t r0 = plans[b].rec0, r1 = r0 + plans[b].nrec;
+            len = E[(size_t)S_NPOS * estride + r1] - E[(size_t)S_NPOS * estride + r0];
+        }
+        uint32_t tot_a, tot_c;
+        const uint32_t ex_a = carry_a16 + block_excl_scan_256((len + 15) >> 4, sh, &tot_a);
+        const uint32_t ex_c = carry_ch + block_excl_scan_256((len + FQZ_CHUNK - 1) / FQZ_CHUNK, sh + 4, &tot_c);
+        if (b < n_blocks) {
+            BlockPlan *p = &plans[b];
+            p->len[S_NPOS] = len;
+            p->a_off[S_NPOS] = ex_a << 4;
+            p->chunk_base[S_NPOS] = ex_c; // nPos chunk ids follow all main chunks
+            atomicAdd(&info->stream_raw[S_NPOS], (unsigned long long)len);
+        }
+        if ((unsigned long long)carry_a16 + tot_a > 0x0FFFFFFFull) overflow = true;
+        carry_a16 += tot_a;
+        carry_ch += tot_c;
     }
-    if (a > npos_cap || chunks > chunk_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; chunks = 0; info->n_main = 0; }
-    info->npos_used = (uint32_t)a;
-    info->n_chunks = chunks;
+    if (t == 0) {
+        const unsigned long long a = (unsigned long long)carry_a16 << 4;
+        uint32_t chunks = carry_ch;
+        if (overflow || a > npos_cap || chunks > chunk_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; chunks = 0; info->n_main = 0; }
+        info->npos_used = (uint32_t)a;
+        info->n_chunks = chunks;
+    }
 }
 
 // ===========================================================================
@@ -832,10 +881,10 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
     }
     launch_scan(ctx, "scan_records", st, E, &info->n_rec, 0, e.rec_cap, 4, estride, partials, pmax); // seq, qual, hdr, plus
-    PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(64), 0, st, info, E, estride, plans, rpb, e.arena_cap, (uint32_t)main_cap));
+    PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(256), 0, st, info, E, estride, plans, rpb, e.arena_cap, (uint32_t)main_cap));
     PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
     launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
-    PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(64), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
+    PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
     PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, npos));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, 1, e.chunk_cap + 1, partials, pmax);

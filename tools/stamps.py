@@ -7,7 +7,7 @@ import torch
 import fastqpacker_amd as fq
 from fastqpacker_amd import compress
 from fastqpacker_amd._lib import lib, check
-text, n = compress.synth_fastq(400000)
+text, n = compress.synth_fastq(int(os.environ.get("FQZ_STAMP_RECORDS", "2849002")))
 dev = torch.device("cuda:0")
 t = torch.from_numpy(text).to(dev)
 out = torch.empty(text.size, dtype=torch.uint8, device=dev)
