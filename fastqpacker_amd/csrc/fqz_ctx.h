@@ -94,6 +94,12 @@ struct DecState {
     DevBuf info, blocks, chunks, streams, rec, partials, tables;
     PinnedBuf h_info, h_blocks;
     uint32_t n_blocks = 0;
+    // arguments of the launch in flight (a decode that guessed the frame layout wrong is relaunched from finish)
+    uint8_t version = 0;
+    int qual_encoding = 0;
+    uint8_t *user_out = nullptr;
+    size_t user_cap = 0;
+    bool general = false;
 };
 
 struct ProfEntry { const char *name; hipEvent_t a, b; };

@@ -105,6 +105,38 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *sh
     return base + incl - v;
 }
 
+// ---- piece-centric kernels (k_split, k_dec_assemble): a lane handles one 16-byte piece of one record's line
+// smallest i with incl[i] > p, for p < incl[63]; every lane of the wave must call it
+__device__ __forceinline__ uint32_t piece_owner(uint32_t incl, uint32_t p)
+{
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = 32; step; step >>= 1) {
+        uint32_t v = (uint32_t)__shfl((int)incl, (int)(lo + step - 1), WAVE);
+        if (v <= p) lo += step;
+    }
+    return lo & 63;
+}
+
+__device__ __forceinline__ void store_piece(uint8_t *dst, const uint32_t w[4], uint32_t nb)
+{
+    if (nb == 16) store_u128_unaligned(dst, make_uint4(w[0], w[1], w[2], w[3]));
+    else
+        for (uint32_t b = 0; b < nb; b++) dst[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+}
+
+// 16 text bytes at text[off..off+16); bytes at or beyond n_text read as 0 (only the very last lines of the text get there)
+__device__ __forceinline__ void load_piece(const uint8_t *text, size_t off, size_t n_text, uint32_t w[4])
+{
+    if (off + 16 <= n_text) {
+        uint4 v = load_u128_unaligned(text + off);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+        w[0] = w[1] = w[2] = w[3] = 0;
+        for (uint32_t b = 0; b < 16 && off + b < n_text; b++) w[b >> 2] |= (uint32_t)text[off + b] << (8 * (b & 3));
+    }
+}
+
 __device__ __forceinline__ int highbit32_d(uint32_t v) { return 31 - __clz(v); }
 
 __device__ __forceinline__ void report_error(EncInfo *info, uint32_t rec, uint32_t order, int code)

@@ -394,37 +394,6 @@ __global__ __launch_bounds__(256) void k_plan2(EncInfo *info, const uint32_t *E,
 // wave-wide load covers ~1 KiB of text.  The piece -> record map is a binary search over a wave scan of the per-record
 // piece counts (ds_bpermute, no LDS allocation).  The nPos payload (rare) is written later by k_npos_write.
 // ---------------------------------------------------------------------------------------------
-// smallest i with incl[i] > p, for p < incl[63]; every lane of the wave must call it
-__device__ __forceinline__ uint32_t piece_owner(uint32_t incl, uint32_t p)
-{
-    uint32_t lo = 0;
-#pragma unroll
-    for (uint32_t step = 32; step; step >>= 1) {
-        uint32_t v = (uint32_t)__shfl((int)incl, (int)(lo + step - 1), WAVE);
-        if (v <= p) lo += step;
-    }
-    return lo & 63;
-}
-
-__device__ __forceinline__ void store_piece(uint8_t *dst, const uint32_t w[4], uint32_t nb)
-{
-    if (nb == 16) store_u128_unaligned(dst, make_uint4(w[0], w[1], w[2], w[3]));
-    else
-        for (uint32_t b = 0; b < nb; b++) dst[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
-}
-
-// 16 text bytes at text[off..off+16); bytes at or beyond n_text read as 0 (only the very last lines of the text get there)
-__device__ __forceinline__ void load_piece(const uint8_t *text, uint32_t off, uint32_t n_text, uint32_t w[4])
-{
-    if (off + 16 <= n_text) {
-        uint4 v = load_u128_unaligned(text + off);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else {
-        w[0] = w[1] = w[2] = w[3] = 0;
-        for (uint32_t b = 0; b < 16 && off + b < n_text; b++) w[b >> 2] |= (uint32_t)text[off + b] << (8 * (b & 3));
-    }
-}
-
 __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text, uint32_t n_text, const uint32_t *__restrict__ ls, EncInfo *info,
                                                uint32_t *E, uint32_t estride, const BlockPlan *__restrict__ plans, uint32_t rpb,
                                                uint8_t *__restrict__ arena)

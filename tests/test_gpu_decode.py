@@ -172,3 +172,32 @@ def test_walk_edge_cases_long_headers_and_records_spanning_tiles(fq):
     bad[0:4] = (hdr[0] + 5).to_bytes(4, "little")    # claims more records than the streams hold
     with pytest.raises(fq.FqzError, match="truncated"):
         fq.compress.decode_block(bytes(bad), 2, 0)
+
+
+def test_foreign_frame_layout_takes_the_general_path(fq):
+    """The decoder sizes its tables from the frame headers (one frame, 16 KiB blocks: what our encoder writes) and
+    verifies that guess while it walks the blocks.  A payload cut differently — here the lengths stream as ONE raw
+    block, and the quality stream as two frames — must still decode (the decoder falls back to the two-walk path)."""
+    import struct
+    text = make_fastq(n_records=10000, seed=31, min_len=100, max_len=100)
+    fqz = O.compress(text, batch_records=10 ** 9)
+    body = fqz[10:]
+    hdr = list(struct.unpack("<9I", body[:36]))   # records, 6 sizes, orig size, reserved (container.go:97-109)
+    sizes = hdr[1:7]
+    pays, pos = [], 36
+    for n in sizes:
+        pays.append(body[pos:pos + n]); pos += n
+    assert pos == len(body)
+
+    def raw_frame(data):
+        assert len(data) < (1 << 17)
+        return b"\x28\xb5\x2f\xfd" + bytes([0x80, 0x38]) + struct.pack("<I", len(data)) + \
+            struct.pack("<I", 1 | (0 << 1) | (len(data) << 3))[:3] + data
+
+    lengths = struct.pack("<I", 100) * 10000                 # 40 000 bytes: 3 chunks expected, 1 block found
+    pays[5] = raw_frame(lengths)
+    qual = O.zstd_decompress(pays[1], 10000 * 100)
+    pays[1] = O.entropy_encode(qual[:300000]) + O.entropy_encode(qual[300000:])   # two concatenated frames
+    hdr[1:7] = [len(p) for p in pays]
+    block = struct.pack("<9I", *hdr) + b"".join(pays)
+    assert fq.compress.decode_block(block, 2, 0) == text
