@@ -118,11 +118,20 @@ __device__ __forceinline__ uint32_t piece_owner(uint32_t incl, uint32_t p)
     return lo & 63;
 }
 
+// the first nb (<= 16) bytes of w[] to dst (any alignment): one 128-bit store, or for a tail at most four stores of
+// 8 / 4 / 2 / 1 bytes — never a byte loop (a divergent 15-iteration loop per tail piece cost more than the whole rest)
 __device__ __forceinline__ void store_piece(uint8_t *dst, const uint32_t w[4], uint32_t nb)
 {
-    if (nb == 16) store_u128_unaligned(dst, make_uint4(w[0], w[1], w[2], w[3]));
-    else
-        for (uint32_t b = 0; b < nb; b++) dst[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+    if (nb >= 16) { store_u128_unaligned(dst, make_uint4(w[0], w[1], w[2], w[3])); return; }
+    unsigned long long cur = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+    if (nb & 8) {
+        __builtin_memcpy(dst, &cur, 8);
+        dst += 8;
+        cur = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+    }
+    if (nb & 4) { uint32_t v = (uint32_t)cur; __builtin_memcpy(dst, &v, 4); dst += 4; cur >>= 32; }
+    if (nb & 2) { uint16_t v = (uint16_t)cur; __builtin_memcpy(dst, &v, 2); dst += 2; cur >>= 16; }
+    if (nb & 1) *dst = (uint8_t)cur;
 }
 
 // 16 text bytes at text[off..off+16); bytes at or beyond n_text read as 0 (only the very last lines of the text get there)

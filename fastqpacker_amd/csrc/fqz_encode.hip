@@ -464,8 +464,10 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
                 const uint32_t nb = (have + 3) >> 2;
                 uint8_t *o = arena + dst + 4 * k;
                 if (nb == 4) store_u32_unaligned(o, out);
-                else
-                    for (uint32_t b = 0; b < nb; b++) o[b] = (uint8_t)(out >> (8 * b));
+                else { // 1..3 packed bytes at the end of a read
+                    if (nb & 2) { uint16_t v = (uint16_t)out; __builtin_memcpy(o, &v, 2); }
+                    if (nb & 1) o[nb & 2] = (uint8_t)(out >> (8 * (nb & 2)));
+                }
                 if (beyond) report_error(info, g * 64 + i, 4, FQZ_E_LONG_N);
                 if (nn) atomicAdd(&Enpos[g * 64 + i], 2 * nn);
             }
