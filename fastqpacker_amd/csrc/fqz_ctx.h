@@ -72,6 +72,7 @@ struct EncState {
     DevBuf ls;        // u32[line_cap+1] line starts
     DevBuf lf;        // u8[line_cap+1] line flags: '\r' before the newline | first-byte class << 1
     DevBuf E;         // u32[5][rec_cap+1]: seq, qual, hdr, plus, npos sizes -> exclusive offsets
+    DevBuf rs_state;  // look-back states of k_record_scan + its ticket
     DevBuf plans;     // BlockPlan[block_cap]
     DevBuf arena;     // seq/qual/hdr/plus/len pre-entropy streams
     DevBuf npos;      // nPos pre-entropy streams

@@ -1,7 +1,7 @@
 // fqz_encode.hip — device-resident encode pipeline (gfx950 / MI355X).
 //
 // Replaces, for a batch of blocks at once, the reference's
-//   fqparser.nextInto/readLine            internal/fqparser/parser.go:136-243   (k_count_nl, k_line_starts, k_record_meta)
+//   fqparser.nextInto/readLine            internal/fqparser/parser.go:136-243   (k_count_nl, k_line_starts, k_record_scan)
 //   encoder.DetectEncoding                internal/encoder/quality.go:22-49     (k_detect)
 //   compressBlockWithBuffers record loop  internal/compress/compress.go:474-520 (k_split_seq, k_split_rest)
 //     encoder.AppendPackedBases           internal/encoder/sequence.go:139-184
@@ -134,39 +134,64 @@ __global__ __launch_bounds__(256) void k_count_nl(const uint8_t *text, uint32_t 
 // Line index + line flags.  Newline j (1-based) ends line j-1 and starts line j:
 //   ls[j] = text offset of line j;  lf[j] = (byte before the newline is '\r') | class of line j's first byte << 1
 // (class 1 = '@', 2 = '+', 0 = anything else / no byte).  With them the record table never touches the text again.
-__global__ __launch_bounds__(256) void k_line_starts(const uint8_t *text, uint32_t n, const uint32_t *tile_off, uint32_t *ls, uint8_t *lf,
-                                                     uint32_t line_cap)
+// A workgroup handles four consecutive 4 KiB tiles (16 bytes per thread each, coalesced); the four per-thread
+// newline counts are scanned together, packed 2 x 16 bits, and every tile adds its own base from the tile scan.
+// The bytes either side of a newline come from registers (neighbouring threads' edge bytes through LDS).
+#define LI_SUB 4u
+__global__ __launch_bounds__(256) void k_line_starts(const uint8_t *__restrict__ text, uint32_t n, uint32_t n_tiles, const uint32_t *__restrict__ tile_off,
+                                                     uint32_t *__restrict__ ls, uint8_t *__restrict__ lf, uint32_t line_cap)
 {
-    __shared__ uint32_t sh[4];
-    __shared__ uint16_t edge[258]; // [t + 1] = first byte | last byte << 8 of thread t; [0] / [257] = the tile's neighbours
-    const uint32_t t = threadIdx.x;
-    uint32_t off = blockIdx.x * FQZ_TILE + t * 16;
-    uint4 v = load_text16(text, off, n);
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    edge[t + 1] = (uint16_t)((w[0] & 0xFF) | ((w[3] >> 24) << 8));
-    if (t == 0) edge[0] = (uint16_t)(off ? (uint32_t)text[off - 1] << 8 : 0);
-    if (t == 255) edge[257] = (uint16_t)(off + 16 < n ? text[off + 16] : 0);
-    uint32_t m[4], c = 0;
+    __shared__ uint32_t sh_lo[4], sh_hi[4], s_ext[2];
+    __shared__ uint16_t edge[LI_SUB][258]; // [q][t + 1] = first byte | last byte << 8 of thread t's 16 bytes of tile q
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const uint32_t tile0 = blockIdx.x * LI_SUB;
+    const uint32_t base = tile0 * FQZ_TILE;
+    uint32_t w[LI_SUB][4], m[LI_SUB][4], c[LI_SUB];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { m[k] = zero_bytes(w[k] ^ 0x0A0A0A0Au); c += __popc(m[k]); }
-    uint32_t tot;
-    uint32_t idx = tile_off[blockIdx.x] + block_excl_scan_256(c, sh, &tot); // (its barriers also publish edge[])
+    for (uint32_t q = 0; q < LI_SUB; q++) {
+        const uint4 v = load_text16(text, base + q * FQZ_TILE + 16 * t, n);
+        w[q][0] = v.x; w[q][1] = v.y; w[q][2] = v.z; w[q][3] = v.w;
+    }
+    if (t == 0) s_ext[0] = base ? text[base - 1] : 0;
+    if (t == 255) s_ext[1] = (size_t)base + LI_SUB * FQZ_TILE < n ? text[base + LI_SUB * FQZ_TILE] : 0;
+#pragma unroll
+    for (uint32_t q = 0; q < LI_SUB; q++) {
+        c[q] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { m[q][k] = zero_bytes(w[q][k] ^ 0x0A0A0A0Au); c[q] += __popc(m[q][k]); }
+        edge[q][t + 1] = (uint16_t)((w[q][0] & 0xFF) | ((w[q][3] >> 24) << 8));
+    }
+    // ---- workgroup scan of the four per-tile counts, packed 2 x 16 bits (a tile holds <= 4096 newlines)
+    const uint32_t lo = c[0] | (c[1] << 16), hi = c[2] | (c[3] << 16);
+    const uint32_t incl_lo = wave_incl_scan(lo), incl_hi = wave_incl_scan(hi);
+    if (lane == 63) { sh_lo[wave] = incl_lo; sh_hi[wave] = incl_hi; }
+    __syncthreads(); // (also publishes edge[] and s_ext[])
+    uint32_t base_lo = 0, base_hi = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+        if (k < wave) { base_lo += sh_lo[k]; base_hi += sh_hi[k]; }
+    const uint32_t ex_lo = base_lo + incl_lo - lo, ex_hi = base_hi + incl_hi - hi; // exclusive, per tile
+    const uint32_t sub_excl[LI_SUB] = {ex_lo & 0xFFFF, ex_lo >> 16, ex_hi & 0xFFFF, ex_hi >> 16};
     if (blockIdx.x == 0 && t == 0) {
         ls[0] = 0;
-        lf[0] = (uint8_t)(n ? (((w[0] & 0xFF) == '@' ? 1 : (w[0] & 0xFF) == '+' ? 2 : 0) << 1) : 0);
+        lf[0] = (uint8_t)(n ? (((w[0][0] & 0xFF) == '@' ? 1 : (w[0][0] & 0xFF) == '+' ? 2 : 0) << 1) : 0);
     }
-    if (c) {
-        const uint32_t prev_b = edge[t] >> 8, next_b = edge[t + 2] & 0xFF;
+#pragma unroll
+    for (uint32_t q = 0; q < LI_SUB; q++) {
+        if (!c[q]) continue; // (tiles at or beyond n_tiles are empty)
+        uint32_t idx = tile_off[tile0 + q] + sub_excl[q];
+        const uint32_t off = base + q * FQZ_TILE + 16 * t;
+        const uint32_t prev_b = t ? (uint32_t)(edge[q][t] >> 8) : (q ? (uint32_t)(edge[q ? q - 1 : 0][256] >> 8) : s_ext[0]);
+        const uint32_t next_b = t < 255 ? (uint32_t)(edge[q][t + 2] & 0xFF) : (q + 1 < LI_SUB ? (uint32_t)(edge[q + 1 < LI_SUB ? q + 1 : q][1] & 0xFF) : s_ext[1]);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t mk = m[k];
+            uint32_t mk = m[q][k];
             while (mk) {
                 const int bit = __ffs(mk) - 1; // 7, 15, 23, 31
                 mk &= mk - 1;
                 const uint32_t b = (uint32_t)bit >> 3;
-                // the bytes either side of the newline, from registers
-                const uint32_t before = b ? (w[k] >> (8 * b - 8)) & 0xFF : (k ? w[k ? k - 1 : 0] >> 24 : prev_b);
-                const uint32_t after = b < 3 ? (w[k] >> (8 * b + 8)) & 0xFF : (k < 3 ? w[k < 3 ? k + 1 : 3] & 0xFF : next_b);
+                const uint32_t before = b ? (w[q][k] >> (8 * b - 8)) & 0xFF : (k ? w[q][k ? k - 1 : 0] >> 24 : prev_b);
+                const uint32_t after = b < 3 ? (w[q][k] >> (8 * b + 8)) & 0xFF : (k < 3 ? w[q][k < 3 ? k + 1 : 3] & 0xFF : next_b);
                 idx++;
                 if (idx <= line_cap) {
                     ls[idx] = off + 4 * k + b + 1; // line idx starts after newline idx
@@ -207,41 +232,133 @@ __device__ __forceinline__ void line_span(const uint8_t *text, const uint32_t *l
     *len = l;
 }
 
-// one thread per record: validation + per-record stream sizes, from the line index and line flags alone
-__global__ __launch_bounds__(256) void k_record_meta(const uint32_t *ls, const uint8_t *lf, EncInfo *info, uint32_t *E, uint32_t estride,
-                                                     uint32_t final_batch)
+// Record table in one pass: validation (parser.go:136-183), per-record stream sizes, and their exclusive prefix sums
+// (the offsets of every record in the seq / qual / headers / plus streams), all from the line index and line flags.
+// A workgroup owns 4096 records (a wave 1024 consecutive ones, 16 coalesced rows of 64).  The sums of the tiles before it come from a
+// decoupled look-back (wave w resolves column w); tiles are handed out by an atomic ticket so that every predecessor
+// of a running tile is running or done.  state[tile][column] = flag << 62 | value (1 = tile sum, 2 = inclusive
+// prefix).  Large tiles keep the look-back chain short (the prefix front advances 64 tiles per memory round trip);
+// the record sizes are computed twice (sums, then offsets) rather than kept in 64 registers.
+#define RS_PER 16u
+#define RS_TILE (256u * RS_PER)
+#define RS_AGG (1ull << 62)
+#define RS_PREFIX (2ull << 62)
+#define RS_VALUE ((1ull << 62) - 1)
+// sizes of record r (< n_rec) in the four streams; reports its format errors when `check`
+__device__ __forceinline__ void record_sizes(const uint32_t *__restrict__ ls, const uint8_t *__restrict__ lf, EncInfo *info, uint32_t r, bool check,
+                                             uint32_t out[4])
 {
-    uint32_t n_rec = info->n_rec;
-    uint32_t n_lines = info->n_lines;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n_rec; r += gridDim.x * blockDim.x) {
-        if (r == n_rec) {
+    const uint4 s4 = *(const uint4 *)(ls + 4 * (size_t)r); // ls is 16-byte aligned
+    const uint32_t s_next = ls[4 * (size_t)r + 4];
+    const uint32_t f4 = *(const uint32_t *)(lf + 4 * (size_t)r), f_next = lf[4 * (size_t)r + 4];
+    // length without '\n' and without one trailing '\r' (the flag implies a non-empty line)
+    uint32_t l0 = s4.y - 1 - s4.x - ((f4 >> 8) & 1);
+    uint32_t l1 = s4.z - 1 - s4.y - ((f4 >> 16) & 1);
+    uint32_t l2 = s4.w - 1 - s4.z - ((f4 >> 24) & 1);
+    uint32_t l3 = s_next - 1 - s4.w - (f_next & 1);
+    if (l0 == 0 || ((f4 >> 1) & 3) != 1) { if (check) report_error(info, r, 0, FQZ_E_HDR_AT); l0 = 1; }
+    if (l2 == 0 || ((f4 >> 17) & 3) != 2) { if (check) report_error(info, r, 1, FQZ_E_SEP_PLUS); l2 = 1; }
+    if (check && l1 != l3) report_error(info, r, 2, FQZ_E_LEN_MISMATCH);
+    uint32_t H = l0 - 1, P = l2 - 1;
+    if (H > 65535u || P > 65535u) { if (check) report_error(info, r, 3, FQZ_E_FIELD_WRAP); H &= 0xFFFF; P &= 0xFFFF; }
+    out[S_SEQ] = (l1 + 3) >> 2;
+    out[S_QUAL] = l1;
+    out[S_HDR] = 2 + H;
+    out[S_PLUS] = 2 + P;
+}
+
+__global__ __launch_bounds__(256) void k_record_scan(const uint32_t *__restrict__ ls, const uint8_t *__restrict__ lf, EncInfo *info, uint32_t *__restrict__ E,
+                                                     uint32_t estride, uint32_t final_batch, unsigned long long *state, uint32_t *ticket)
+{
+    __shared__ uint32_t s_tile, shw[4][4], s_excl[4];
+    const uint32_t n_rec = info->n_rec, n_lines = info->n_lines;
+    if ((unsigned long long)blockIdx.x * RS_TILE > n_rec) return; // exactly the tiles that hold a record index <= n_rec take a ticket
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    if (t == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    // wave w owns the records [rw, rw + 64 * RS_PER): row j = records rw + 64 j + lane (coalesced loads and stores)
+    const uint32_t rw = tile * RS_TILE + wave * (64 * RS_PER);
+    uint32_t tsum[4] = {0, 0, 0, 0};
+    for (uint32_t j = 0; j < RS_PER; j++) {
+        const uint32_t r = rw + 64 * j + lane;
+        if (r < n_rec) {
+            uint32_t v[4];
+            record_sizes(ls, lf, info, r, true, v);
+#pragma unroll
+            for (int c = 0; c < 4; c++) tsum[c] += v[c];
+        } else if (r == n_rec && final_batch && info->status == 0) {
             // a trailing partial record (final batch only): the lines that exist are still
             // validated before EOF is hit (parser.go:138-165), then it is dropped (parser.go:196-199)
-            if (final_batch && info->status == 0) {
-                uint32_t have = n_lines - 4 * n_rec; // 0..3 complete lines
-                if (have >= 1 && (lf[4 * r] >> 1) != 1) report_error(info, r, 0, FQZ_E_HDR_AT);
-                if (have >= 3 && (lf[4 * r + 2] >> 1) != 2) report_error(info, r, 1, FQZ_E_SEP_PLUS);
-            }
-            break;
+            uint32_t have = n_lines - 4 * n_rec; // 0..3 complete lines
+            if (have >= 1 && (lf[4 * (size_t)r] >> 1) != 1) report_error(info, r, 0, FQZ_E_HDR_AT);
+            if (have >= 3 && (lf[4 * (size_t)r + 2] >> 1) != 2) report_error(info, r, 1, FQZ_E_SEP_PLUS);
         }
-        const uint4 s4 = *(const uint4 *)(ls + 4 * r); // ls is 16-byte aligned
-        const uint32_t s_next = ls[4 * r + 4];
-        const uint32_t f4 = *(const uint32_t *)(lf + 4 * r), f_next = lf[4 * r + 4];
-        // length without '\n' and without one trailing '\r' (the flag implies a non-empty line)
-        uint32_t l0 = s4.y - 1 - s4.x - ((f4 >> 8) & 1);
-        uint32_t l1 = s4.z - 1 - s4.y - ((f4 >> 16) & 1);
-        uint32_t l2 = s4.w - 1 - s4.z - ((f4 >> 24) & 1);
-        uint32_t l3 = s_next - 1 - s4.w - (f_next & 1);
-        if (l0 == 0 || ((f4 >> 1) & 3) != 1) { report_error(info, r, 0, FQZ_E_HDR_AT); l0 = 1; }
-        if (l2 == 0 || ((f4 >> 17) & 3) != 2) { report_error(info, r, 1, FQZ_E_SEP_PLUS); l2 = 1; }
-        if (l1 != l3) report_error(info, r, 2, FQZ_E_LEN_MISMATCH);
-        uint32_t H = l0 - 1, P = l2 - 1;
-        if (H > 65535u || P > 65535u) { report_error(info, r, 3, FQZ_E_FIELD_WRAP); H &= 0xFFFF; P &= 0xFFFF; }
-        E[(size_t)S_SEQ * estride + r] = (l1 + 3) >> 2;
-        E[(size_t)S_QUAL * estride + r] = l1;
-        E[(size_t)S_HDR * estride + r] = 2 + H;
-        E[(size_t)S_PLUS * estride + r] = 2 + P;
-        E[(size_t)S_NPOS * estride + r] = 2; // u16 count; the sequence stage adds 2 bytes per N position
+    }
+    // ---- totals per wave, then per workgroup
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t ws = wave_sum(tsum[c]);
+        if (lane == 0) shw[wave][c] = ws;
+    }
+    __syncthreads();
+    uint32_t wbase[4], btot[4]; // sum of the waves before this one, tile total
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint32_t base = 0, tot = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { if (k < wave) base += shw[k][c]; tot += shw[k][c]; }
+        wbase[c] = base;
+        btot[c] = tot;
+    }
+    // ---- decoupled look-back: wave w resolves column w
+    {
+        const uint32_t c = wave;
+        const uint32_t tot = c == 0 ? btot[0] : c == 1 ? btot[1] : c == 2 ? btot[2] : btot[3];
+        unsigned long long excl = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(&state[(size_t)tile * 4 + c], RS_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int look = (int)tile - 1;
+            for (;;) {
+                const int idx = look - (int)lane;
+                const unsigned long long sv = idx >= 0 ? __hip_atomic_load(&state[(size_t)idx * 4 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_PREFIX;
+                const uint32_t flag = (uint32_t)(sv >> 62);
+                const unsigned long long pmask = __ballot(flag == 2), zmask = __ballot(flag == 0);
+                const int fp = pmask ? __ffsll((long long)pmask) - 1 : 64;          // nearest predecessor with a full prefix
+                const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1); // lanes 0..fp must have published
+                if (zmask & need) { __builtin_amdgcn_s_sleep(2); continue; }
+                unsigned long long part = (int)lane <= fp ? (sv & RS_VALUE) : 0ull;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, WAVE);
+                excl += part;
+                if (pmask) break;
+                look -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&state[(size_t)tile * 4 + c], RS_PREFIX | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl[c] = (uint32_t)excl; // stream offsets inside a batch fit 32 bits (checked by k_plan1)
+        }
+    }
+    __syncthreads();
+    // ---- offsets: row by row, a wave scan per column with the running sum carried in a wave-uniform register
+    uint32_t carry[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) carry[c] = s_excl[c] + wbase[c];
+    for (uint32_t j = 0; j < RS_PER; j++) {
+        const uint32_t r = rw + 64 * j + lane;
+        if (rw + 64 * j > n_rec) break; // (wave-uniform)
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (r < n_rec) {
+            record_sizes(ls, lf, info, r, false, v); // (line index and flags come from L2 this time)
+            E[(size_t)S_NPOS * estride + r] = 2;     // u16 count; the sequence stage adds 2 bytes per N position
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t inc = wave_incl_scan(v[c]);
+            if (r <= n_rec) E[(size_t)c * estride + r] = carry[c] + inc - v[c]; // [n_rec] = total
+            carry[c] += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
     }
 }
 
@@ -810,6 +927,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.ls.ensure(4ull * (e.line_cap + 8)))) return rc;
     if ((rc = e.lf.ensure(e.line_cap + 8))) return rc;
     if ((rc = e.E.ensure(4ull * 5 * estride))) return rc;
+    if ((rc = e.rs_state.ensure(8ull * (4ull * (e.rec_cap / RS_TILE + 1) + 1)))) return rc;
     if ((rc = e.plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
     if ((rc = e.arena.ensure(e.arena_cap + 64))) return rc;
     if ((rc = e.npos.ensure(e.npos_cap + 64))) return rc;
@@ -836,7 +954,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if (e.n_tiles) {
         PROF(ctx, st, "k_count_nl", hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile));
         launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, 1, e.n_tiles + 1, partials, pmax);
-        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile, ls, lf, e.line_cap));
+        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts, dim3((e.n_tiles + LI_SUB - 1) / LI_SUB), dim3(256), 0, st, d_text, n, e.n_tiles, tile, ls, lf, e.line_cap));
     } else {
         HIP_TRY(hipMemsetAsync(tile, 0, 8, st));
         HIP_TRY(hipMemsetAsync(ls, 0, 8, st));
@@ -844,14 +962,17 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     }
     PROF(ctx, st, "k_setup_records", hipLaunchKernelGGL(k_setup_records, dim3(1), dim3(64), 0, st, info, tile, e.n_tiles, ls, e.line_cap, e.rec_cap, e.block_cap, rpb,
                        final_batch, n));
-    uint32_t rec_grid = (e.rec_cap + 255) / 256;
-    if (rec_grid > 4096) rec_grid = 4096;
-    PROF(ctx, st, "k_record_meta", hipLaunchKernelGGL(k_record_meta, dim3(rec_grid), dim3(256), 0, st, ls, lf, info, E, estride, final_batch));
+    {
+        const uint32_t rs_tiles = e.rec_cap / RS_TILE + 1;
+        unsigned long long *rs_state = e.rs_state.as<unsigned long long>();
+        HIP_TRY(hipMemsetAsync(rs_state, 0, 8ull * (4ull * rs_tiles + 1), st));
+        PROF(ctx, st, "k_record_scan", hipLaunchKernelGGL(k_record_scan, dim3(rs_tiles), dim3(256), 0, st, ls, lf, info, E, estride, final_batch, rs_state,
+                                                        (uint32_t *)(rs_state + 4ull * rs_tiles)));
+    }
     if (qual_encoding == FQZ_DETECT_ENCODING) {
         PROF(ctx, st, "k_detect", hipLaunchKernelGGL(k_detect, dim3(grid_for_waves(rpb < e.rec_cap ? rpb : e.rec_cap)), dim3(256), 0, st, d_text, ls, info, rpb));
         hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
     }
-    launch_scan(ctx, "scan_records", st, E, &info->n_rec, 0, e.rec_cap, 4, estride, partials, pmax); // seq, qual, hdr, plus
     PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(256), 0, st, info, E, estride, plans, rpb, e.arena_cap, (uint32_t)main_cap));
     PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
     launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
