@@ -73,12 +73,12 @@ struct EncState {
     DevBuf lf;        // u8[line_cap+1] line flags: '\r' before the newline | first-byte class << 1
     DevBuf E;         // u32[5][rec_cap+1]: seq, qual, hdr, plus, npos sizes -> exclusive offsets
     DevBuf rs_state;  // look-back states of k_record_scan + its ticket
+    DevBuf scan_state; // look-back states of k_scan + its ticket
     DevBuf plans;     // BlockPlan[block_cap]
     DevBuf arena;     // seq/qual/hdr/plus/len pre-entropy streams
     DevBuf npos;      // nPos pre-entropy streams
     DevBuf slots;     // chunk_cap * FQZ_SLOT
     DevBuf csize;     // u32[chunk_cap+1] -> exclusive prefix
-    DevBuf partials;  // scan partial sums
     DevBuf stamps;    // diagnostic s_memtime stamps (FQZ_DBG_STAMPS)
     bool streams_valid = false; // an encode has run: fqz_debug_get_streams can read its streams
     PinnedBuf h_info; // EncInfo

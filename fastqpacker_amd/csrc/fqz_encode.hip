@@ -19,76 +19,92 @@
 #include <string.h>
 
 // ===========================================================================
-// generic in-place exclusive scan of u32 columns (n may live on the device)
+// generic in-place exclusive scan of a u32 array (n may live on the device); data[n] receives the total.
+// One pass: a workgroup owns 4096 elements (a wave 1024 consecutive ones in 16 coalesced rows, kept in registers),
+// the sum of the tiles before it comes from a decoupled look-back over state[] (flag << 62 | value: 1 = tile sum,
+// 2 = inclusive prefix).  Tiles are handed out by an atomic ticket, so every predecessor of a running tile is
+// running or done and the wait always ends.  state[] (tiles + 1 words, the last one is the ticket) must be zero.
 // ===========================================================================
 #define SCAN_ITEMS 16
 #define SCAN_TILE (256 * SCAN_ITEMS)
+#define SC_AGG (1ull << 62)
+#define SC_PREFIX (2ull << 62)
+#define SC_VALUE ((1ull << 62) - 1)
 
 __device__ __forceinline__ uint32_t scan_n(const uint32_t *n_ptr, uint32_t n_add) { return (n_ptr ? *n_ptr : 0u) + n_add; }
 
-__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *data, const uint32_t *n_ptr, uint32_t n_add,
-                                                     uint32_t col_stride, uint32_t *partials, uint32_t pstride)
+__global__ __launch_bounds__(256) void k_scan(uint32_t *__restrict__ data, const uint32_t *n_ptr, uint32_t n_add, unsigned long long *state, uint32_t n_tiles_cap)
 {
-    __shared__ uint32_t sh[4];
-    uint32_t n = scan_n(n_ptr, n_add);
-    uint32_t base = blockIdx.x * SCAN_TILE;
-    if (base >= n) return;
-    const uint32_t *col = data + (size_t)blockIdx.y * col_stride;
-    uint32_t i0 = base + threadIdx.x * SCAN_ITEMS, s = 0;
+    __shared__ uint32_t s_tile, shw[4], s_excl;
+    const uint32_t n = scan_n(n_ptr, n_add);
+    if ((unsigned long long)blockIdx.x * SCAN_TILE > n) return; // exactly the tiles that hold an index <= n take a ticket
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    if (t == 0) s_tile = atomicAdd((uint32_t *)(state + n_tiles_cap), 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t rw = tile * SCAN_TILE + wave * (64 * SCAN_ITEMS);
+    uint32_t v[SCAN_ITEMS], tsum = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { uint32_t i = i0 + k; s += (i < n) ? col[i] : 0u; }
-    uint32_t tot;
-    (void)block_excl_scan_256(s, sh, &tot);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * pstride + blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(256) void k_scan_top(uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t col_stride,
-                                                  uint32_t *partials, uint32_t pstride)
-{
-    __shared__ uint32_t sh[4];
-    uint32_t n = scan_n(n_ptr, n_add);
-    uint32_t nwg = (n + SCAN_TILE - 1) / SCAN_TILE;
-    uint32_t *p = partials + (size_t)blockIdx.x * pstride;
-    uint32_t carry = 0;
-    for (uint32_t b = 0; b < nwg; b += 256) {
-        uint32_t i = b + threadIdx.x;
-        uint32_t v = i < nwg ? p[i] : 0u, tot;
-        uint32_t ex = block_excl_scan_256(v, sh, &tot);
-        if (i < nwg) p[i] = carry + ex;
-        carry += tot;
-        __syncthreads();
+    for (uint32_t j = 0; j < SCAN_ITEMS; j++) {
+        const uint32_t i = rw + 64 * j + lane;
+        v[j] = i < n ? data[i] : 0u;
+        tsum += v[j];
     }
-    if (threadIdx.x == 0) data[(size_t)blockIdx.x * col_stride + n] = carry; // total after the last element
+    const uint32_t ws = wave_sum(tsum);
+    if (lane == 0) shw[wave] = ws;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { if (k < wave) wbase += shw[k]; tot += shw[k]; }
+    if (wave == 0) {
+        unsigned long long excl = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(&state[tile], SC_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int look = (int)tile - 1;
+            for (;;) {
+                const int idx = look - (int)lane;
+                const unsigned long long sv = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SC_PREFIX;
+                const uint32_t flag = (uint32_t)(sv >> 62);
+                const unsigned long long pmask = __ballot(flag == 2), zmask = __ballot(flag == 0);
+                const int fp = pmask ? __ffsll((long long)pmask) - 1 : 64;          // nearest predecessor with a full prefix
+                const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1); // lanes 0..fp must have published
+                if (zmask & need) { __builtin_amdgcn_s_sleep(2); continue; }
+                unsigned long long part = (int)lane <= fp ? (sv & SC_VALUE) : 0ull;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, WAVE);
+                excl += part;
+                if (pmask) break;
+                look -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&state[tile], SC_PREFIX | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = (uint32_t)excl;
+        }
+    }
+    __syncthreads();
+    uint32_t carry = s_excl + wbase;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_ITEMS; j++) {
+        const uint32_t i = rw + 64 * j + lane;
+        const uint32_t inc = wave_incl_scan(v[j]);
+        if (i <= n) data[i] = carry + inc - v[j]; // [n] = total
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_scan_apply(uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t col_stride,
-                                                    const uint32_t *partials, uint32_t pstride)
+// data: n_cap + 1 u32, scanned in place; data[n] receives the total
+static int launch_scan(fqz_ctx *ctx, const char *label, hipStream_t st, uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t n_cap)
 {
-    __shared__ uint32_t sh[4];
-    uint32_t n = scan_n(n_ptr, n_add);
-    uint32_t base = blockIdx.x * SCAN_TILE;
-    if (base >= n) return;
-    uint32_t *col = data + (size_t)blockIdx.y * col_stride;
-    uint32_t i0 = base + threadIdx.x * SCAN_ITEMS, v[SCAN_ITEMS], s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { uint32_t i = i0 + k; v[k] = (i < n) ? col[i] : 0u; s += v[k]; }
-    uint32_t tot;
-    uint32_t ex = block_excl_scan_256(s, sh, &tot) + partials[(size_t)blockIdx.y * pstride + blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { uint32_t i = i0 + k; if (i < n) col[i] = ex; ex += v[k]; }
-}
-
-// data: ncols columns of (cap+1) u32, scanned in place; data[col][n] receives the total
-static void launch_scan(fqz_ctx *ctx, const char *label, hipStream_t st, uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t n_cap, uint32_t ncols,
-                        uint32_t col_stride, uint32_t *partials, uint32_t pstride)
-{
-    uint32_t nwg = (n_cap + SCAN_TILE - 1) / SCAN_TILE;
-    if (nwg == 0) nwg = 1;
+    const uint32_t tiles = n_cap / SCAN_TILE + 1;
+    DevBuf &sb = ctx->enc.scan_state;
+    int rc = sb.ensure(8ull * ((size_t)tiles + 1));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(sb.p, 0, 8ull * ((size_t)tiles + 1), st));
     ctx->prof.begin(label, st);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nwg, ncols), dim3(256), 0, st, data, n_ptr, n_add, col_stride, partials, pstride);
-    hipLaunchKernelGGL(k_scan_top, dim3(ncols), dim3(256), 0, st, data, n_ptr, n_add, col_stride, partials, pstride);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nwg, ncols), dim3(256), 0, st, data, n_ptr, n_add, col_stride, partials, pstride);
+    hipLaunchKernelGGL(k_scan, dim3(tiles), dim3(256), 0, st, data, n_ptr, n_add, sb.as<unsigned long long>(), tiles);
     ctx->prof.end(st);
+    return FQZ_OK;
 }
 
 // ===========================================================================
@@ -933,10 +949,6 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.npos.ensure(e.npos_cap + 64))) return rc;
     if ((rc = e.slots.ensure((size_t)e.chunk_cap * FQZ_SLOT))) return rc;
     if ((rc = e.csize.ensure(4ull * (e.chunk_cap + 2)))) return rc;
-    uint32_t pmax = e.rec_cap / SCAN_TILE + 2;
-    if (e.n_tiles / SCAN_TILE + 2 > pmax) pmax = e.n_tiles / SCAN_TILE + 2;
-    if (e.chunk_cap / SCAN_TILE + 2 > pmax) pmax = e.chunk_cap / SCAN_TILE + 2;
-    if ((rc = e.partials.ensure(4ull * 5 * pmax))) return rc;
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
     if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
 
@@ -946,14 +958,14 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     EncInfo *info = e.info.as<EncInfo>();
     uint32_t *tile = e.tile_cnt.as<uint32_t>(), *ls = e.ls.as<uint32_t>(), *E = e.E.as<uint32_t>();
     uint8_t *lf = e.lf.as<uint8_t>();
-    uint32_t *partials = e.partials.as<uint32_t>(), *csize = e.csize.as<uint32_t>();
+    uint32_t *csize = e.csize.as<uint32_t>();
     BlockPlan *plans = e.plans.as<BlockPlan>();
     uint8_t *arena = e.arena.as<uint8_t>(), *npos = e.npos.as<uint8_t>(), *slots = e.slots.as<uint8_t>();
 
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, qual_encoding);
     if (e.n_tiles) {
         PROF(ctx, st, "k_count_nl", hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile));
-        launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, 1, e.n_tiles + 1, partials, pmax);
+        if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles))) return rc;
         PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts, dim3((e.n_tiles + LI_SUB - 1) / LI_SUB), dim3(256), 0, st, d_text, n, e.n_tiles, tile, ls, lf, e.line_cap));
     } else {
         HIP_TRY(hipMemsetAsync(tile, 0, 8, st));
@@ -975,11 +987,11 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     }
     PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(256), 0, st, info, E, estride, plans, rpb, e.arena_cap, (uint32_t)main_cap));
     PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
-    launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, 1, estride, partials, pmax);
+    if ((rc = launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap))) return rc;
     PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
     PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, npos));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
-    launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, 1, e.chunk_cap + 1, partials, pmax);
+    if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out));
     HIP_TRY(hipGetLastError());
@@ -1085,7 +1097,6 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     if ((rc = e.plans.ensure(sizeof(BlockPlan) * 2))) return rc;
     if ((rc = e.slots.ensure((size_t)(chunks + 1) * FQZ_SLOT))) return rc;
     if ((rc = e.csize.ensure(4ull * (chunks + 2)))) return rc;
-    if ((rc = e.partials.ensure(4ull * (chunks / SCAN_TILE + 2)))) return rc;
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
     EncInfo *info = e.info.as<EncInfo>();
     BlockPlan *plans = e.plans.as<BlockPlan>();
@@ -1093,7 +1104,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, 0);
     hipLaunchKernelGGL(k_single_plan, dim3(1), dim3(64), 0, st, info, plans, (uint32_t)n);
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
-    launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks, 1, chunks + 1, e.partials.as<uint32_t>(), chunks / SCAN_TILE + 2);
+    if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;
     hipLaunchKernelGGL(k_single_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_dst, cap);
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, d_dst));
     HIP_TRY(hipGetLastError());
