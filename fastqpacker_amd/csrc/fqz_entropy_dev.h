@@ -66,177 +66,115 @@ __device__ __forceinline__ void wave_lds_sync()
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane)); }
 
 // ---------------------------------------------------------------------------------------------
-// FSE compression of the Huffman weights, executed by wave 0 (all 64 lanes, uniform control flow).
-// w: S.w[0..nw) ; returns the compressed size (uniform): 0 = not compressible, 1 = single symbol.
-// Output bytes land in sc->tree[1..].  Mirrors oracle fse_compress_weights().
-// Everything on the sequential path is wave-uniform so that hipcc keeps it on the scalar unit:
-// counts come from ballots, per-position transforms are looked up in parallel beforehand, the
-// state tables sit in VGPR lanes (v_readlane with an SGPR index) and output dwords are collected
-// with v_writelane.
+// FSE compression of the Huffman weights (only for alphabets with more than 128 weights).
+// FQZ-H1 does not fit a distribution to the weights of every chunk: it picks one of two fixed normalised
+// distributions over the weight values 0..11 (table log 5) by the share of zero weights.  The NCount header and
+// the compression tables of both are compile-time constants; what is left per chunk is the encoding itself.
+// Mirrors oracle fse_compress_weights().
 // ---------------------------------------------------------------------------------------------
-struct UBits { // LSB-first bit writer with uniform state; dword k of the stream ends up in lane k of `v`
-    unsigned long long acc;
-    int nb;
-    int wpos;
-    int v;
+#define FSE_W_LOG 5
+#define FSE_W_SIZE 32
+struct FseFixed {
+    uint16_t state_table[FSE_W_SIZE];
+    int dnb[12], dfs[12];
+    uint8_t nc[8]; // FSE NCount header
+    uint32_t nc_len;
 };
-__device__ __forceinline__ void ub_put(UBits &b, uint32_t val, int n)
+constexpr int fse_highbit(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; }
+constexpr FseFixed make_fse_fixed(int n0, int n1, int n2, int n3, int n4, int n5, int n6, int n7, int n8, int n9, int n10, int n11)
 {
-    b.acc |= (unsigned long long)val << b.nb;
-    b.nb += n;
-    if (b.nb >= 32) {
-        b.v = ((int)lane_id() == b.wpos) ? (int)(uint32_t)b.acc : b.v; // v_cndmask: no branch
-        b.wpos++;
-        b.acc >>= 32;
-        b.nb -= 32;
+    FseFixed f{};
+    const int norm[12] = {n0, n1, n2, n3, n4, n5, n6, n7, n8, n9, n10, n11};
+    const int table_log = FSE_W_LOG, table_size = FSE_W_SIZE, alphabet = 12;
+    { // FSE_writeNCount (all counts are >= 1 here, so there are no zero runs)
+        uint32_t bits = 0, outp = 0;
+        int bc = 0, remaining = table_size + 1, threshold = table_size, nb = table_log + 1, sym = 0;
+        bits += (uint32_t)(table_log - 5) << bc; bc += 4;
+        while (sym < alphabet && remaining > 1) {
+            int c = norm[sym++];
+            int max = (2 * threshold - 1) - remaining;
+            remaining -= c;
+            c++;
+            if (c >= threshold) c += max;
+            bits += (uint32_t)c << bc;
+            bc += nb;
+            bc -= (c < max) ? 1 : 0;
+            while (remaining < threshold) { nb--; threshold >>= 1; }
+            if (bc > 16) { f.nc[outp++] = (uint8_t)bits; f.nc[outp++] = (uint8_t)(bits >> 8); bits >>= 16; bc -= 16; }
+        }
+        if (bc > 0) f.nc[outp++] = (uint8_t)bits;
+        if (bc > 8) f.nc[outp++] = (uint8_t)(bits >> 8);
+        f.nc_len = outp;
     }
+    { // FSE_buildCTable
+        int cumul[13] = {};
+        uint8_t table_symbol[FSE_W_SIZE] = {};
+        for (int s = 1; s <= alphabet; s++) cumul[s] = cumul[s - 1] + norm[s - 1];
+        const int step = (table_size >> 1) + (table_size >> 3) + 3, mask = table_size - 1;
+        int pos = 0;
+        for (int s = 0; s < alphabet; s++)
+            for (int i = 0; i < norm[s]; i++) { table_symbol[pos] = (uint8_t)s; pos = (pos + step) & mask; }
+        for (int u = 0; u < table_size; u++) { int sy = table_symbol[u]; f.state_table[cumul[sy]++] = (uint16_t)(table_size + u); }
+        int total = 0;
+        for (int s = 0; s < alphabet; s++) {
+            if (norm[s] == 1) { f.dnb[s] = (table_log << 16) - table_size; f.dfs[s] = total - 1; total++; }
+            else {
+                const int max_bits_out = table_log - fse_highbit((uint32_t)(norm[s] - 1));
+                f.dnb[s] = (max_bits_out << 16) - (norm[s] << max_bits_out);
+                f.dfs[s] = total - norm[s];
+                total += norm[s];
+            }
+        }
+    }
+    return f;
 }
-__device__ __forceinline__ uint32_t ub_close(UBits &b) // returns total bits; flushes the partial dword
-{
-    uint32_t total = (uint32_t)b.wpos * 32u + (uint32_t)b.nb;
-    if (b.nb) { b.v = ((int)lane_id() == b.wpos) ? (int)(uint32_t)b.acc : b.v; b.wpos++; }
-    return total;
-}
+__constant__ const FseFixed c_fse_fixed[2] = {
+    make_fse_fixed(21, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1), // sparse alphabets: at least half of the weights are 0
+    make_fse_fixed(1, 1, 2, 3, 5, 6, 5, 3, 2, 2, 1, 1),  // dense alphabets
+};
 
-// The whole workgroup calls this.  Wave 0 builds the tables (uniform, scalar); the two interleaved state
-// chains (even / odd weight positions, walked from the last weight to the first) are inherently sequential, so
-// they are cut into chunks and every chunk is simulated for EVERY possible start state in parallel
-// (2 chains x 4 chunks x 32 states = 256 lanes, or 2 x 2 x 64); the true start states are then chained through
-// the end-state maps and 8 (4) lanes replay their chunk recording the emitted bits; assembly is parallel again.
+// The whole workgroup calls this.  The two interleaved state chains (even / odd weight positions, walked from the
+// last weight to the first) are inherently sequential, so they are cut into 4 chunks each and every chunk is
+// simulated for EVERY possible start state in parallel (2 chains x 4 chunks x 32 states = 256 lanes); the true
+// start states are then chained through the end-state maps, every weight position looks up the state it is
+// encoded from in the recorded trace, and the bit stream is assembled with a wave scan.
+// Returns the compressed size (valid in wave 0): 0 = nothing to code.
 __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc, int n_in, unsigned long long *stamps = nullptr)
 {
 #define FSE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
     const int n = __builtin_amdgcn_readfirstlane(n_in);
     const uint32_t t = threadIdx.x, wave = t >> 6;
     const int lane = (int)(t & 63);
-    // S.misc[22]: 0 = go on, else 1 + early result; [23] table_log; [24] NCount bytes
+    if (n <= 2) return 0;
+    // S.misc[24] NCount bytes
     if (wave == 0) {
-        int wv[4];
+        int zeros = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) { int idx = lane + 64 * j; wv[j] = idx < n ? (int)S.w[idx] : 255; }
-        int cnt[13];
-#pragma unroll
-        for (int v = 0; v < 13; v++) {
-            int c = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) c += (int)__popcll(__ballot(wv[j] == v));
-            cnt[v] = c;
-        }
-        int maxw = 0, maxc = 0, present = 0, largest = 0;
-#pragma unroll
-        for (int v = 0; v < 13; v++) { if (cnt[v]) { maxw = v; present++; } }
-#pragma unroll
-        for (int v = 0; v < 13; v++) { if (cnt[v] > maxc) { maxc = cnt[v]; largest = v; } } // first maximum = lowest symbol
-        int early = 0;
-        if (n <= 2) early = 1;            // result 0
-        else if (maxc == n) early = 2;    // result 1: single symbol
-        else if (maxc == 1) early = 1;    // result 0: not compressible
-        if (early) { if (lane == 0) S.misc[22] = (uint32_t)early; }
-        else {
-            int table_log = 6;
-            {
-                int max_bits_src = highbit32_d((uint32_t)(n - 1)) - 2;
-                int min_bits_src = highbit32_d((uint32_t)n) + 1;
-                int min_bits_sym = highbit32_d((uint32_t)maxw) + 2;
-                int min_bits = min_bits_src < min_bits_sym ? min_bits_src : min_bits_sym;
-                if (max_bits_src < table_log) table_log = max_bits_src;
-                if (min_bits > table_log) table_log = min_bits;
-                if (table_log < 5) table_log = 5;
-                if (table_log > 6) table_log = 6;
-            }
-            const int table_size = 1 << table_log;
-            // lane v owns weight symbol v: normalised count and its exclusive prefix
-            int my_cnt = 0;
-#pragma unroll
-            for (int v = 0; v < 13; v++) if (lane == v) my_cnt = cnt[v];
-            const int R = table_size - present;
-            int e = my_cnt ? (my_cnt * R) / n : 0;
-            int my_norm = my_cnt ? 1 + e : 0;
-            int given = (int)wave_sum((uint32_t)e);
-            if (lane == largest) my_norm += R - given;
-            int my_cumul = (int)wave_incl_scan((uint32_t)my_norm) - my_norm;
-            if (lane < 16) { sc->norm[lane] = my_norm; sc->cumul[lane] = my_cumul; }
-            wave_lds_sync();
-            // ---- FSE_writeNCount as a plain LSB-first bit stream (same bytes as the 16-bit-flush original); one lane
-            if (lane == 0) {
-                uint8_t *ncb = (uint8_t *)sc->nc_bits;
-                unsigned long long acc = 0;
-                int nbacc = 0;
-                uint32_t outp = 0;
-                int remaining = table_size + 1, threshold = table_size, nb = table_log + 1, prev0 = 0, run = 0;
-                acc = (unsigned long long)(table_log - 5); nbacc = 4;
-                for (int v = 0; v <= maxw && remaining > 1; v++) {
-                    int nv = sc->norm[v];
-                    if (prev0 && nv == 0) { run++; continue; }
-                    if (prev0) { // close the zero run: 2-bit repeat codes
-                        while (run >= 3) { acc |= 3ull << nbacc; nbacc += 2; run -= 3; }
-                        acc |= (unsigned long long)run << nbacc; nbacc += 2;
-                        run = 0;
-                    }
-                    int c = nv;
-                    int max = (2 * threshold - 1) - remaining;
-                    remaining -= c;
-                    c++;
-                    if (c >= threshold) c += max;
-                    acc |= (unsigned long long)c << nbacc;
-                    nbacc += nb - (c < max ? 1 : 0);
-                    prev0 = (c == 1);
-                    while (remaining < threshold) { nb--; threshold >>= 1; }
-                    while (nbacc >= 8) { ncb[outp++] = (uint8_t)acc; acc >>= 8; nbacc -= 8; }
-                }
-                while (nbacc > 0) { ncb[outp++] = (uint8_t)acc; acc >>= 8; nbacc -= 8; }
-                S.misc[24] = outp;
-            }
-            // ---- FSE_buildCTable: lane u owns table position u
-            const int mask = table_size - 1;
-            const int inv = table_size == 32 ? 7 : 3; // step^-1 mod table_size (step 23: 23*7 = 161; step 43: 43*3 = 129)
-            {
-                int k = (lane * inv) & mask; // spread order index of position `lane`: pos_k = (k*step) & mask
-                int my_sym = 0;              // = number of symbols whose range ends at or before k
-                for (int v = 0; v < 12; v++) my_sym += (sc->cumul[v + 1] <= k && v + 1 <= maxw) ? 1 : 0;
-                int rank = 0;
-#pragma unroll
-                for (int v = 0; v < 13; v++) {
-                    unsigned long long bm = __ballot(lane < table_size && my_sym == v);
-                    if (my_sym == v) rank = (int)__popcll(bm & ((1ull << lane) - 1));
-                }
-                if (lane < table_size) sc->state_table[sc->cumul[my_sym] + rank] = (uint16_t)(table_size + lane);
-            }
-            if (lane < 13) {
-                int nv = my_norm, dnb, dfs;
-                if (nv == 0) { dnb = ((table_log + 1) << 16) - table_size; dfs = 0; }
-                else if (nv == 1) { dnb = (table_log << 16) - table_size; dfs = my_cumul - 1; }
-                else {
-                    int mbo = table_log - highbit32_d((uint32_t)(nv - 1));
-                    dnb = (mbo << 16) - (nv << mbo);
-                    dfs = my_cumul - nv;
-                }
-                sc->dnb[lane] = dnb;
-                sc->dfs[lane] = dfs;
-            }
-            wave_lds_sync();
-            // FSE_initCState2 for the last two positions: no output
-            if (lane < 2) {
-                const int i = n - 1 - lane;
-                int sy = S.w[i], dnb = sc->dnb[sy], dfs = sc->dfs[sy];
-                uint32_t nb_out = (uint32_t)(dnb + (1 << 15)) >> 16;
-                uint32_t value = (nb_out << 16) - (uint32_t)dnb;
-                sc->start[i & 1][0] = sc->state_table[(value >> nb_out) + (uint32_t)dfs];
-            }
-            if (lane == 0) { S.misc[22] = 0; S.misc[23] = (uint32_t)table_log; }
+        for (int j = 0; j < 4; j++) { const int idx = lane + 64 * j; zeros += (int)__popcll(__ballot(idx < n && S.w[idx] == 0)); }
+        const FseFixed &F = c_fse_fixed[2 * zeros >= n ? 0 : 1];
+        if (lane < FSE_W_SIZE) sc->state_table[lane] = F.state_table[lane];
+        if (lane < 12) { sc->dnb[lane] = F.dnb[lane]; sc->dfs[lane] = F.dfs[lane]; }
+        if (lane < 8) ((uint8_t *)sc->nc_bits)[lane] = F.nc[lane];
+        if (lane == 0) S.misc[24] = F.nc_len;
+        wave_lds_sync();
+        // FSE_initCState2 for the last two positions: no output
+        if (lane < 2) {
+            const int i = n - 1 - lane;
+            int sy = S.w[i], dnb = sc->dnb[sy], dfs = sc->dfs[sy];
+            uint32_t nb_out = (uint32_t)(dnb + (1 << 15)) >> 16;
+            uint32_t value = (nb_out << 16) - (uint32_t)dnb;
+            sc->start[i & 1][0] = sc->state_table[(value >> nb_out) + (uint32_t)dfs];
         }
     }
     __syncthreads();
     FSE_STAMP(12);
-    if (S.misc[22]) return S.misc[22] - 1;
-    const int table_log = (int)S.misc[23], table_size = 1 << table_log;
+    const int table_log = FSE_W_LOG, table_size = FSE_W_SIZE;
     const int top = n - 3;                      // highest position that emits bits
-    const int nq = 128 / table_size;            // chunks per chain: 4 (32 states) or 2 (64 states)
+    const int nq = 128 / table_size;            // chunks per chain: 4
     const int CH = 128 / nq;                    // steps per chunk
     // chain c holds the positions of parity c, walked downwards: step k <-> position top_c - 2k.
-    // trace[c][q][k][u] = state after step k of chunk q when the chunk is entered in state u (table_size == 32 only)
+    // trace[c][q][k][u] = state after step k of chunk q when the chunk is entered in state u
     uint8_t *trace = lds_trace(S);
-    const bool traced = table_size == 32;
     {
         const int c = (int)(t >> 7), q = (int)((t & 127) / (uint32_t)table_size), u = (int)(t & (uint32_t)(table_size - 1));
         const int top_c = ((top & 1) == c) ? top : top - 1;
@@ -247,7 +185,7 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
             int sy = S.w[p];
             uint32_t nb = (st + (uint32_t)sc->dnb[sy]) >> 16;
             st = sc->state_table[(st >> nb) + (uint32_t)sc->dfs[sy]];
-            if (traced) tr[k * 32] = (uint8_t)st;
+            tr[k * 32] = (uint8_t)st;
         }
         sc->endmap[c][q][u] = (uint8_t)(st - (uint32_t)table_size);
     }
@@ -263,8 +201,7 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
     }
     sc->rec[t] = 0;
     __syncthreads();
-    if (traced) {
-        // every weight position looks up the state it is encoded from and derives its output bits
+    { // every weight position looks up the state it is encoded from and derives its output bits
         const int p = (int)t;
         if (p <= top) {
             const int c = p & 1, top_c = ((top & 1) == c) ? top : top - 1;
@@ -274,17 +211,6 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
             const int sy = S.w[p];
             const uint32_t nb = (st + (uint32_t)sc->dnb[sy]) >> 16;
             sc->rec[p] = (st & ((1u << nb) - 1)) | (nb << 16);
-        }
-    } else if ((t & (uint32_t)(table_size - 1)) == 0) { // 64-state tables: one lane per chunk replays it from its true start state
-        const int c = (int)(t >> 7), q = (int)((t & 127) / (uint32_t)table_size);
-        const int top_c = ((top & 1) == c) ? top : top - 1;
-        uint32_t st = sc->start[c][q];
-        int p = top_c - 2 * q * CH;
-        for (int k = 0; k < CH && p >= 0; k++, p -= 2) {
-            int sy = S.w[p];
-            uint32_t nb = (st + (uint32_t)sc->dnb[sy]) >> 16;
-            sc->rec[p] = (st & ((1u << nb) - 1)) | (nb << 16);
-            st = sc->state_table[(st >> nb) + (uint32_t)sc->dfs[sy]];
         }
     }
     __syncthreads();
@@ -553,7 +479,7 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint8_t *src, const ui
             uint32_t h = fse_weights_wg(S, sc, (int)nw, stamps); // all four waves; the size is valid in wave 0
             if (t == 0) {
                 uint32_t ts = 0;
-                if (h > 1 && h < nw / 2) { sc->tree[0] = (uint8_t)h; ts = h + 1; }
+                if (h > 1 && h < 128) { sc->tree[0] = (uint8_t)h; ts = h + 1; } // header byte < 128 = size of the FSE-compressed weights
                 S.misc[6] = ts;
             }
             __syncthreads();

@@ -144,41 +144,27 @@ static inline uint8_t *bw_close(bitw *b) /* end mark 1 + pad */
     return b->p;
 }
 
-/* returns compressed size, 0 = not compressible, 1 = single symbol (caller falls back) */
+/* FQZ-H1 does not fit a distribution to the weights of every chunk: it picks one of two fixed normalised
+ * distributions over the weight values 0..11 (table log 5), by the share of zero weights (absent symbols).  The
+ * compressed description grows by ~15 bytes per chunk against a fitted table, and the encoder saves the serial
+ * count / normalise / NCount / table-build steps — 15 % of the GPU entropy kernel.  (A zstd encoder is free to
+ * choose any normalised counts; the decoder reads them from the NCount header as usual.) */
+#define FSE_W_LOG 5
+static const int FSE_W_NORM[2][12] = {
+    {21, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},  /* sparse alphabets: at least half of the weights are 0 */
+    {1, 1, 2, 3, 5, 6, 5, 3, 2, 2, 1, 1},   /* dense alphabets */
+};
+
+/* returns compressed size, 0 = nothing to code (caller falls back) */
 static size_t fse_compress_weights(const uint8_t *w, int n, uint8_t *dst)
 {
-    if (n <= 1) return 0;
-    int cnt[13] = {0}, maxw = 0, maxc = 0;
-    for (int i = 0; i < n; i++) { cnt[w[i]]++; if (w[i] > maxw) maxw = w[i]; }
-    for (int s = 0; s <= maxw; s++) if (cnt[s] > maxc) maxc = cnt[s];
-    if (maxc == n) return 1;
-    if (maxc == 1) return 0;
-
-    /* table log as FSE_optimalTableLog(6, n, maxw) */
-    int table_log = FSE_W_MAXLOG;
-    {
-        int max_bits_src = highbit32((uint32_t)(n - 1)) - 2;
-        int min_bits_src = highbit32((uint32_t)n) + 1;
-        int min_bits_sym = highbit32((uint32_t)maxw) + 2;
-        int min_bits = min_bits_src < min_bits_sym ? min_bits_src : min_bits_sym;
-        if (max_bits_src < table_log) table_log = max_bits_src;
-        if (min_bits > table_log) table_log = min_bits;
-        if (table_log < 5) table_log = 5;
-        if (table_log > FSE_W_MAXLOG) table_log = FSE_W_MAXLOG;
-    }
-    int table_size = 1 << table_log;
-
-    /* normalisation (ours): every present symbol gets 1, the rest pro rata,
-     * leftover to the most frequent (lowest symbol on ties) */
-    int norm[13] = {0}, present = 0, largest = 0;
-    for (int s = 0; s <= maxw; s++) {
-        if (cnt[s]) present++;
-        if (cnt[s] > cnt[largest]) largest = s;
-    }
-    int R = table_size - present, given = 0;
-    for (int s = 0; s <= maxw; s++)
-        if (cnt[s]) { int e = (cnt[s] * R) / n; norm[s] = 1 + e; given += e; }
-    norm[largest] += R - given;
+    if (n <= 2) return 0;
+    int zeros = 0;
+    for (int i = 0; i < n; i++) zeros += (w[i] == 0);
+    const int *fixed = FSE_W_NORM[2 * zeros >= n ? 0 : 1];
+    const int maxw = 11, table_log = FSE_W_LOG, table_size = 1 << FSE_W_LOG;
+    int norm[13] = {0};
+    for (int s = 0; s <= maxw; s++) norm[s] = fixed[s];
 
     /* FSE_writeNCount */
     uint8_t *op = dst;
@@ -279,7 +265,7 @@ size_t fqzo_huf_write_tree(const uint8_t nbits[256], int max_bits, uint8_t *dst)
     }
     uint8_t tmp[300];
     size_t h = fse_compress_weights(w, nw, tmp);
-    if (h > 1 && h < (size_t)nw / 2) {
+    if (h > 1 && h < 128) { /* header byte < 128 = size of the FSE-compressed weights */
         dst[0] = (uint8_t)h;
         memcpy(dst + 1, tmp, h);
         return h + 1;
