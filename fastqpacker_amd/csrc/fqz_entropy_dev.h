@@ -75,9 +75,9 @@ __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_rea
 #define FSE_W_LOG 5
 #define FSE_W_SIZE 32
 struct FseFixed {
-    uint16_t state_table[FSE_W_SIZE];
-    int dnb[12], dfs[12];
-    uint8_t nc[8]; // FSE NCount header
+    uint16_t trans[FSE_W_SIZE * 12]; // [state - 32][weight] = next state | bits to emit << 8  (FSE_encodeSymbol)
+    uint8_t init_state[12];          // FSE_initCState2: first state for a given last weight (no output)
+    uint8_t nc[8];                   // FSE NCount header
     uint32_t nc_len;
 };
 constexpr int fse_highbit(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; }
@@ -114,16 +114,27 @@ constexpr FseFixed make_fse_fixed(int n0, int n1, int n2, int n3, int n4, int n5
         int pos = 0;
         for (int s = 0; s < alphabet; s++)
             for (int i = 0; i < norm[s]; i++) { table_symbol[pos] = (uint8_t)s; pos = (pos + step) & mask; }
-        for (int u = 0; u < table_size; u++) { int sy = table_symbol[u]; f.state_table[cumul[sy]++] = (uint16_t)(table_size + u); }
+        uint16_t state_table[FSE_W_SIZE] = {};
+        int dnb[12] = {}, dfs[12] = {};
+        for (int u = 0; u < table_size; u++) { int sy = table_symbol[u]; state_table[cumul[sy]++] = (uint16_t)(table_size + u); }
         int total = 0;
         for (int s = 0; s < alphabet; s++) {
-            if (norm[s] == 1) { f.dnb[s] = (table_log << 16) - table_size; f.dfs[s] = total - 1; total++; }
+            if (norm[s] == 1) { dnb[s] = (table_log << 16) - table_size; dfs[s] = total - 1; total++; }
             else {
                 const int max_bits_out = table_log - fse_highbit((uint32_t)(norm[s] - 1));
-                f.dnb[s] = (max_bits_out << 16) - (norm[s] << max_bits_out);
-                f.dfs[s] = total - norm[s];
+                dnb[s] = (max_bits_out << 16) - (norm[s] << max_bits_out);
+                dfs[s] = total - norm[s];
                 total += norm[s];
             }
+        }
+        for (int s = 0; s < alphabet; s++) {
+            for (int st = table_size; st < 2 * table_size; st++) {
+                const uint32_t nb = ((uint32_t)st + (uint32_t)dnb[s]) >> 16;
+                f.trans[(st - table_size) * 12 + s] = (uint16_t)(state_table[(st >> nb) + dfs[s]] | (nb << 8));
+            }
+            const uint32_t nb_out = (uint32_t)(dnb[s] + (1 << 15)) >> 16;
+            const uint32_t value = (nb_out << 16) - (uint32_t)dnb[s];
+            f.init_state[s] = (uint8_t)state_table[(value >> nb_out) + dfs[s]];
         }
     }
     return f;
@@ -151,21 +162,17 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
         int zeros = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) { const int idx = lane + 64 * j; zeros += (int)__popcll(__ballot(idx < n && S.w[idx] == 0)); }
-        const FseFixed &F = c_fse_fixed[2 * zeros >= n ? 0 : 1];
-        if (lane < FSE_W_SIZE) sc->state_table[lane] = F.state_table[lane];
-        if (lane < 12) { sc->dnb[lane] = F.dnb[lane]; sc->dfs[lane] = F.dfs[lane]; }
+        const int prof = 2 * zeros >= n ? 0 : 1;
+        const FseFixed &F = c_fse_fixed[prof];
         if (lane < 8) ((uint8_t *)sc->nc_bits)[lane] = F.nc[lane];
-        if (lane == 0) S.misc[24] = F.nc_len;
-        wave_lds_sync();
+        if (lane == 0) { S.misc[24] = F.nc_len; S.misc[23] = (uint32_t)prof; }
         // FSE_initCState2 for the last two positions: no output
-        if (lane < 2) {
-            const int i = n - 1 - lane;
-            int sy = S.w[i], dnb = sc->dnb[sy], dfs = sc->dfs[sy];
-            uint32_t nb_out = (uint32_t)(dnb + (1 << 15)) >> 16;
-            uint32_t value = (nb_out << 16) - (uint32_t)dnb;
-            sc->start[i & 1][0] = sc->state_table[(value >> nb_out) + (uint32_t)dfs];
-        }
+        if (lane < 2) { const int i = n - 1 - lane; sc->start[i & 1][0] = F.init_state[S.w[i]]; }
     }
+    __syncthreads();
+    // the transition table of the chosen distribution, into the (by now dead) Huffman node array
+    uint16_t *trans = (uint16_t *)sc->cnt;
+    if (t < FSE_W_SIZE * 12 / 2) ((uint32_t *)trans)[t] = ((const uint32_t *)c_fse_fixed[S.misc[23]].trans)[t];
     __syncthreads();
     FSE_STAMP(12);
     const int table_log = FSE_W_LOG, table_size = FSE_W_SIZE;
@@ -178,15 +185,17 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
     {
         const int c = (int)(t >> 7), q = (int)((t & 127) / (uint32_t)table_size), u = (int)(t & (uint32_t)(table_size - 1));
         const int top_c = ((top & 1) == c) ? top : top - 1;
-        uint32_t st = (uint32_t)(table_size + u);
+        uint32_t st = (uint32_t)u; // state - 32
         int p = top_c - 2 * q * CH;
         uint8_t *tr = trace + ((c * 4 + q) * 32) * 32 + u;
+        uint32_t sy = p >= 0 ? S.w[p] : 0u; // the weight of the next step is fetched one step ahead: one dependent LDS read per step
         for (int k = 0; k < CH && p >= 0; k++, p -= 2) {
-            int sy = S.w[p];
-            uint32_t nb = (st + (uint32_t)sc->dnb[sy]) >> 16;
-            st = sc->state_table[(st >> nb) + (uint32_t)sc->dfs[sy]];
-            tr[k * 32] = (uint8_t)st;
+            const uint32_t sy_next = p >= 2 ? S.w[p - 2] : 0u;
+            st = (trans[st * 12 + sy] & 0xFFu) - (uint32_t)table_size;
+            tr[k * 32] = (uint8_t)(st + (uint32_t)table_size);
+            sy = sy_next;
         }
+        st += (uint32_t)table_size;
         sc->endmap[c][q][u] = (uint8_t)(st - (uint32_t)table_size);
     }
     __syncthreads();
@@ -209,7 +218,7 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
             const uint32_t s0 = sc->start[c][q];
             const uint32_t st = k ? (uint32_t)trace[(((c * 4 + q) * 32) + (k - 1)) * 32 + (int)(s0 - 32u)] : s0;
             const int sy = S.w[p];
-            const uint32_t nb = (st + (uint32_t)sc->dnb[sy]) >> 16;
+            const uint32_t nb = (uint32_t)trans[(st - 32u) * 12 + (uint32_t)sy] >> 8;
             sc->rec[p] = (st & ((1u << nb) - 1)) | (nb << 16);
         }
     }
