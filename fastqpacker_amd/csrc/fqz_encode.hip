@@ -684,7 +684,7 @@ __device__ __forceinline__ void locate_chunk(const EncInfo *info, const BlockPla
     *cidx = chunk - p->chunk_base[s];
 }
 
-__global__ __launch_bounds__(256) void k_entropy(const EncInfo *info, const BlockPlan *plans, const uint8_t *arena, const uint8_t *npos_arena,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_entropy(const EncInfo *info, const BlockPlan *plans, const uint8_t *arena, const uint8_t *npos_arena,
                                                  uint8_t *slots, uint32_t *csize, int dbg_stop, unsigned long long *stamps)
 {
     __shared__ __attribute__((aligned(16))) EntropyLds S;

@@ -396,23 +396,61 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint8_t *src, const ui
         DBG_STOP(3);
         const uint32_t n = n_active;
         const uint32_t *key = sorted + (256 - n);
-        if (t < n) sc->cnt[t] = key[t] >> 8;
-        __syncthreads();
-        // ---- two-queue Huffman merge, leaf preferred on ties (one lane)
-        if (t == 0) {
-            uint32_t li = 0, ih = n, it = n;
-            uint32_t cl = sc->cnt[0], ci = 0; // head weights of the leaf and internal queues
-            for (uint32_t k = 0; k + 1 < n; k++) {
-                uint32_t a, b, ca, cb2;
-                if (li < n && (ih >= it || cl <= ci)) { a = li++; ca = cl; cl = li < n ? sc->cnt[li] : 0; }
-                else { a = ih++; ca = ci; ci = ih < it ? sc->cnt[ih] : 0; }
-                if (li < n && (ih >= it || cl <= ci)) { b = li++; cb2 = cl; cl = li < n ? sc->cnt[li] : 0; }
-                else { b = ih++; cb2 = ci; ci = ih < it ? sc->cnt[ih] : 0; }
-                sc->cnt[it] = ca + cb2;
-                if (ih == it) ci = ca + cb2; // the new node is the head of an empty internal queue
-                sc->parent[a] = (uint16_t)it;
-                sc->parent[b] = (uint16_t)it;
-                it++;
+        // ---- two-queue Huffman merge, leaf preferred on ties: n - 1 dependent steps.  Up to 128 active symbols
+        //      (always, for FASTQ streams) wave 0 runs it on the scalar unit: the sorted leaf weights and the internal
+        //      node weights sit in VGPR lanes (node i in lane i % 64 of register i / 64) and are fetched with
+        //      v_readlane into SGPRs, all queue state is wave-uniform; only the parent links go to LDS.
+        if (n <= 128) {
+            if (wave == 0) {
+                const uint32_t INF = 0xFFFFFFFFu;
+                const int nn = __builtin_amdgcn_readfirstlane((int)n);
+                const uint32_t lw0 = lane < n ? key[lane] >> 8 : INF, lw1 = lane + 64 < n ? key[lane + 64] >> 8 : INF;
+                uint32_t iw0 = INF, iw1 = INF;
+#define HQ_FETCH(v0, v1, idx, lim) ((idx) < (lim) ? (uint32_t)(((idx) & 64) ? rl((int)(v1), (idx) & 63) : rl((int)(v0), (idx) & 63)) : INF)
+                int li = 0, ih = 0, it = 0; // leaves taken, internal nodes taken / made (internal node j has id nn + j)
+                uint32_t cl = HQ_FETCH(lw0, lw1, 0, nn), ci = INF;
+                for (int k = 0; k + 1 < nn; k++) {
+                    const bool la = cl <= ci;
+                    const int a = la ? li : nn + ih;
+                    const uint32_t ca = la ? cl : ci;
+                    li += la ? 1 : 0;
+                    ih += la ? 0 : 1;
+                    cl = HQ_FETCH(lw0, lw1, li, nn);
+                    ci = HQ_FETCH(iw0, iw1, ih, it);
+                    const bool lb = cl <= ci;
+                    const int b = lb ? li : nn + ih;
+                    const uint32_t cb2 = lb ? cl : ci;
+                    li += lb ? 1 : 0;
+                    ih += lb ? 0 : 1;
+                    cl = HQ_FETCH(lw0, lw1, li, nn);
+                    ci = HQ_FETCH(iw0, iw1, ih, it);
+                    const uint32_t sum = ca + cb2;
+                    iw0 = ((int)lane == (it & 63) && it < 64) ? sum : iw0; // v_cndmask: no branch
+                    iw1 = ((int)lane == (it & 63) && it >= 64) ? sum : iw1;
+                    if (ih == it) ci = sum; // the new node is the head of an empty internal queue
+                    if (lane == 0) { sc->parent[a] = (uint16_t)(nn + it); sc->parent[b] = (uint16_t)(nn + it); }
+                    it++;
+                }
+#undef HQ_FETCH
+            }
+        } else {
+            if (t < n) sc->cnt[t] = key[t] >> 8;
+            __syncthreads();
+            if (t == 0) {
+                uint32_t li = 0, ih = n, it = n;
+                uint32_t cl = sc->cnt[0], ci = 0; // head weights of the leaf and internal queues
+                for (uint32_t k = 0; k + 1 < n; k++) {
+                    uint32_t a, b, ca, cb2;
+                    if (li < n && (ih >= it || cl <= ci)) { a = li++; ca = cl; cl = li < n ? sc->cnt[li] : 0; }
+                    else { a = ih++; ca = ci; ci = ih < it ? sc->cnt[ih] : 0; }
+                    if (li < n && (ih >= it || cl <= ci)) { b = li++; cb2 = cl; cl = li < n ? sc->cnt[li] : 0; }
+                    else { b = ih++; cb2 = ci; ci = ih < it ? sc->cnt[ih] : 0; }
+                    sc->cnt[it] = ca + cb2;
+                    if (ih == it) ci = ca + cb2; // the new node is the head of an empty internal queue
+                    sc->parent[a] = (uint16_t)it;
+                    sc->parent[b] = (uint16_t)it;
+                    it++;
+                }
             }
         }
         __syncthreads();
