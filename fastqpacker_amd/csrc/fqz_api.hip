@@ -99,7 +99,7 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     for (DevBuf *b : eb) b->release();
     e.h_info.release(); e.h_plans.release();
     DecState &d = c->dec;
-    DevBuf *db[] = {&d.info, &d.blocks, &d.chunks, &d.streams, &d.rec, &d.partials, &d.tables};
+    DevBuf *db[] = {&d.info, &d.blocks, &d.chunks, &d.streams, &d.rec, &d.partials, &d.tables, &d.lz_scratch};
     for (DevBuf *b : db) b->release();
     d.h_info.release(); d.h_blocks.release();
     c->prof.collect();

@@ -92,7 +92,7 @@ struct DecState {
     size_t out_cap = 0;
     hipStream_t stream = nullptr;
     bool in_flight = false;
-    DevBuf info, blocks, chunks, streams, rec, partials, tables;
+    DevBuf info, blocks, chunks, streams, rec, partials, tables, lz_scratch;
     PinnedBuf h_info, h_blocks;
     uint32_t n_blocks = 0;
     // arguments of the launch in flight (a decode that guessed the frame layout wrong is relaunched from finish)

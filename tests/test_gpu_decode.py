@@ -201,3 +201,59 @@ def test_foreign_frame_layout_takes_the_general_path(fq):
     hdr[1:7] = [len(p) for p in pays]
     block = struct.pack("<9I", *hdr) + b"".join(pays)
     assert fq.compress.decode_block(block, 2, 0) == text
+
+
+def _lz_cases():
+    rng = np.random.default_rng(77)
+    text = make_fastq(n_records=3000, seed=41, min_len=100, max_len=151, n_frac=0.01)
+    words = [b"ACGT", b"GATTACA", b"TTTT", b"@SEQ_ID_", b" length=", b"\n+\n", b"IIIIIIII", b"1:N:0:ATCACG"]
+    cases = {
+        "fastq_text": text,                                                   # literals + matches, several blocks
+        "repeats": b"".join(words[i] for i in rng.integers(0, len(words), 60000)),
+        "zeros": b"\x00" * 300000,                                           # RLE-like: one long overlapping match
+        "short_period": (b"ab" * 70000) + b"c" + (b"xyz" * 50000),         # offset < match length
+        "random": bytes(rng.integers(0, 256, 200000, dtype=np.uint8)),       # raw blocks
+        "skewed": bytes(rng.choice(256, 150000, p=np.array([0.6] + [0.4 / 255] * 255)).astype(np.uint8)),
+        "tiny": b"hello hello hello hello",
+        "one": b"x",
+    }
+    return cases
+
+
+@pytest.mark.parametrize("level", [1, 3, 19])
+def test_foreign_zstd_frames_with_lz_sequences(fq, level):
+    """frames written by another zstd encoder (here the system libzstd, which plays the role of the
+    klauspost encoder of the stock fqpack) carry LZ sequences; the GPU decodes them block by block."""
+    for name, data in _lz_cases().items():
+        frame = O.zstd_compress(data, level)
+        assert fq.compress.entropy_decode(frame, len(data)) == data, (name, level)
+    # a corrupted frame is refused
+    frame = bytearray(O.zstd_compress(_lz_cases()["fastq_text"], level))
+    frame[len(frame) // 2] ^= 0x55
+    try:
+        out = fq.compress.entropy_decode(bytes(frame), len(_lz_cases()["fastq_text"]))
+        assert out != _lz_cases()["fastq_text"]      # (a flipped literal byte can still be a valid stream)
+    except fq.FqzError:
+        pass
+
+
+def test_stock_style_container_decodes(fq):
+    """A .fqz block whose six payloads were produced by a general zstd encoder (what the stock fqpack writes) decodes to
+    the same text as the oracle pipeline."""
+    import struct
+    text = make_fastq(n_records=20000, seed=43, min_len=80, max_len=151, n_frac=0.02)
+    fqz = O.compress(text, batch_records=10 ** 9)
+    body = fqz[10:]
+    hdr = list(struct.unpack("<9I", body[:36]))
+    pays, pos = [], 36
+    for n in hdr[1:7]:
+        pays.append(body[pos:pos + n]); pos += n
+    recs, nrec = O.parse_all(text)
+    streams, _ = O.split_block(text, recs, nrec, 0)
+    order = [0, 1, 2, 3, 4, 5]  # wire order = seq, qual, headers, plus, nPos, lengths = stream order of the oracle
+    new = [O.zstd_compress(streams[k], 1) if len(streams[k]) else b"" for k in order]
+    hdr[1:7] = [len(p) for p in new]
+    block = struct.pack("<9I", *hdr) + b"".join(new)
+    assert fq.compress.decode_block(block, 2, 0) == text
+    # and whole-file: header + block through Decompress
+    assert fq.compress.Decompress(fqz[:10] + block) == text
