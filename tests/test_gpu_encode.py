@@ -125,3 +125,16 @@ def test_parser_errors_match_reference_messages(fq):
     # dropped unterminated tail (App. B-3)
     block, n = fq.compress.encode_block(b"@r1\nACGT\n+\nIIII\n@r2\nAC\n+\nII")
     assert n == 1
+
+
+def test_ragged_phred64_default_blocks_match_oracle_and_round_trip(fq):
+    """BASELINE config 5 shape (35-301 bp, 5 % N in runs, Phred+64, plus payloads) at the real block size:
+    120 000 records = 1.2 blocks of 100 000.  Whole-file bytes == oracle pipeline, and the text round-trips
+    through both decoders."""
+    text = make_fastq(n_records=120000, seed=99, min_len=35, max_len=301, n_frac=0.05, phred=64, plus_payload=True)
+    z = fq.compress.Compress(text)
+    want = O.compress(text)
+    assert len(z) == len(want) and z == want
+    assert z[9] & 0x02                                # FlagPhred64 detected from block 0 (quality.go:43-45, container.go:16)
+    assert fq.compress.Decompress(z) == text
+    assert O.decompress(z) == text
