@@ -16,7 +16,7 @@ lines = []
 stats = glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "rocprofv3_kernel_stats_bench_steps5.csv"))
-    lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu --decode-steps 1")
+    lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu --decode-steps 1 --inflight 0")
     for r in csv.DictReader(open(stats[0])):
         lines.append("%-34s calls %5s total_ns %12s avg_ns %12s pct %6s" % (r.get("Name", "")[:34], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 pmc = {}
