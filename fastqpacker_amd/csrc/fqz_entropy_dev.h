@@ -12,7 +12,7 @@
 //
 // Work split inside the workgroup:
 //   all 256 lanes : histogram, rank sort, leaf depths, weights, canonical codes, bit packing
-//   lane 0        : the two-queue Huffman merge (n_active-1 dependent steps)
+//   wave 0, scalar: the two-queue Huffman merge (n_active-1 dependent steps; weights in VGPR lanes, v_readlane)
 //   all four waves: the FSE compression of the weights (speculative chains, see fse_weights_wg)
 #pragma once
 #include "fqz_device.h"
@@ -24,11 +24,8 @@ struct HufScratch {          // aliases the (not yet used) output staging buffer
     uint16_t parent[512];
     uint8_t l[256];          // code lengths in sorted order
     uint8_t tree[272];       // Huffman_Tree_Description
-    uint16_t state_table[64];
     uint32_t fse_bits[64];   // FSE bitstream of the weights (dword aligned)
-    uint32_t nc_bits[8];     // FSE NCount header bits
-    int dnb[16], dfs[16];    // FSE symbol transforms (deltaNbBits, deltaFindState)
-    int norm[16], cumul[16]; // normalised weight counts and their exclusive prefix
+    uint32_t nc_bits[8];     // FSE NCount header bytes
     uint32_t start[2][4];    // true start state of every chunk of the two state chains
     uint32_t fin[2];         // final states (flushed at the end of the stream)
     uint32_t rec[256];       // bits | nbits << 16 emitted at each weight position
