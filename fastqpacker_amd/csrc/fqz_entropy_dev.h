@@ -287,30 +287,11 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint8_t *src, const ui
                                      const int dbg_stop = 0, unsigned long long *stamps = nullptr)
 {
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    // ---- stage the chunk in LDS with coalesced 128-bit loads (bytes at or beyond m read as 0)
-    {
-        uint4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) { // all four loads in flight before the first use
-            const uint32_t off = (t + 256 * q) * 16;
-            const uint32_t have = off < m ? (m - off < 16 ? m - off : 16) : 0;
-            v[q] = make_uint4(0, 0, 0, 0);
-            if (have == 16) v[q] = *(const uint4 *)(src + off);
-            else if (have) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint32_t k = 0; k < have; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
-                v[q] = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-        }
-        S.ctab[t] = 0;
-        if (t < OUT_WORDS - FQZ_CHUNK / 4) S.out[FQZ_CHUNK / 4 + t] = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) *(uint4 *)&S.out[(t + 256 * q) * 4] = v[q];
-    }
-    __syncthreads();
-    // ---- my symbols -> registers; byte histogram.  Skewed data (quality deltas are ~90 % zeros) would serialise LDS
-    //      atomics on one bin, so every wave first peels off its dominant byte: the candidate is the first byte the wave
-    //      sees, matches are counted with SWAR compares in registers and added once per wave.
+    // ---- my symbols -> registers (see "symbol ownership").  The kernel is bound by the LDS pipeline (histogram atomics,
+    //      code table lookups, bit packing), so a full chunk does not touch LDS on its way in: lane l of wave w owns the
+    //      64 consecutive bytes at 4096 w + 64 l and loads them straight from global memory (4 x 128 bit; the four
+    //      loads of a wave cover the same 32 cache lines, the vector L1 merges them).  Partial chunks (the last one of a
+    //      stream) have odd stream lengths and go through a staged copy in the not-yet-used output buffer.
     const uint32_t nstreams = m >= 256 ? 4 : 1;
     const uint32_t seg = nstreams == 4 ? (m + 3) / 4 : m;
     const uint32_t seg_base = wave * seg;
@@ -322,10 +303,39 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint8_t *src, const ui
     if (sym_b > seg_len) sym_b = seg_len;
     const uint32_t cnt = sym_b - sym_a;
     uint32_t sym[16];
-    {
+    S.ctab[t] = 0;
+    if (m == FQZ_CHUNK) {
+        const uint4 *p = (const uint4 *)(src + 4096 * wave + 64 * lane);
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        sym[0] = a.x; sym[1] = a.y; sym[2] = a.z; sym[3] = a.w; sym[4] = b.x; sym[5] = b.y; sym[6] = b.z; sym[7] = b.w;
+        sym[8] = c.x; sym[9] = c.y; sym[10] = c.z; sym[11] = c.w; sym[12] = d.x; sym[13] = d.y; sym[14] = d.z; sym[15] = d.w;
+        __syncthreads(); // the zeroed histogram
+    } else {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { // all four loads in flight before the first use; bytes at or beyond m read as 0
+            const uint32_t off = (t + 256 * q) * 16;
+            const uint32_t have = off < m ? (m - off < 16 ? m - off : 16) : 0;
+            v[q] = make_uint4(0, 0, 0, 0);
+            if (have == 16) v[q] = *(const uint4 *)(src + off);
+            else if (have) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; k < have; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
+                v[q] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        if (t < OUT_WORDS - FQZ_CHUNK / 4) S.out[FQZ_CHUNK / 4 + t] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) *(uint4 *)&S.out[(t + 256 * q) * 4] = v[q];
+        __syncthreads();
         const uint8_t *mine = (const uint8_t *)S.out + seg_base + sym_a;
 #pragma unroll
         for (int d = 0; d < 16; d++) sym[d] = 4u * d < cnt ? lds_load_u32_unaligned(mine + 4 * d) : 0u;
+    }
+    // ---- byte histogram.  Skewed data (quality deltas are ~90 % zeros) would serialise LDS atomics on one bin, so every
+    //      wave first peels off its dominant byte: the candidate is the first byte the wave sees, matches are counted with
+    //      SWAR compares in registers and added once per wave.
+    {
         const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sym[0] & 0xFF)); // wave-uniform candidate byte
         const uint32_t cand4 = cand * 0x01010101u;
         uint32_t n_cand = 0;
