@@ -242,6 +242,8 @@ def compress(fastq, block_size=0, workers=1, batch_records=0, entropy=0) -> byte
     """compress.Compress on a memory buffer (bytes or numpy uint8 array)."""
     a = np.frombuffer(fastq, dtype=np.uint8) if not isinstance(fastq, np.ndarray) else fastq
     cap = lib().fqzo_compress_bound(a.size)
+    if batch_records:  # tiny blocks: 36-byte block headers and six frame headers per block dwarf the library's bound
+        cap += (int(np.count_nonzero(a == 10)) // 4 // batch_records + 2) * 160
     out = np.empty(cap, dtype=np.uint8)
     opt = Options(block_size, workers, batch_records, entropy)
     r = lib().fqzo_compress(a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, C.byref(opt))

@@ -1,0 +1,71 @@
+"""Randomised GPU-vs-oracle parity: many small inputs with odd shapes through the whole C ABI pipeline."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fastq_gen import make_fastq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fq():
+    import fastqpacker_amd as fq
+    fq.lib()
+    return fq
+
+
+def _cases():
+    rng = np.random.default_rng(20240607)
+    out = []
+    for i in range(60):
+        n = int(rng.choice([1, 2, 3, 7, 63, 64, 65, 127, 300, 1000, 2500]))
+        lo = int(rng.choice([0, 1, 4, 15, 16, 17, 35, 63, 64, 100, 151]))
+        hi = lo + int(rng.choice([0, 1, 3, 16, 50, 300, 1100]))
+        out.append(dict(n_records=n, seed=1000 + i, min_len=lo, max_len=hi, n_frac=float(rng.choice([0, 0, 0.01, 0.2, 1.0])),
+                        phred=int(rng.choice([33, 33, 64])), plus_payload=bool(rng.integers(0, 2)), crlf=bool(rng.random() < 0.15),
+                        block=int(rng.choice([1, 3, 64, 100, 1000, 100000]))))
+    return out
+
+
+def _gpu_encode_blocks(fq, text, block, enc):
+    """device-resident batch encode with `block` records per block (the pipeline itself always batches 100 000)"""
+    import torch
+    dev = torch.device("cuda:0")
+    t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev) if len(text) else torch.empty(0, dtype=torch.uint8, device=dev)
+    out = torch.empty(len(text) * 2 + 65536, dtype=torch.uint8, device=dev)
+    res = fq.compress.encode_batch_dev(t.data_ptr() if len(text) else 0, len(text), out.data_ptr(), out.numel(), records_per_block=block,
+                                       qual_encoding=enc, final=True)
+    return out[: res.out_len].cpu().numpy().tobytes(), res
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: "n%d_L%d-%d_b%d" % (c["n_records"], c["min_len"], c["max_len"], c["block"]))
+def test_random_shapes_match_oracle(fq, case):
+    case = dict(case)
+    block = case.pop("block")
+    text = make_fastq(**case)
+    want = O.compress(text, batch_records=block)            # 10-byte file header + blocks of `block` records
+    enc = 1 if want[9] & 0x02 else 0                        # what DetectEncoding decided on block 0
+    body, res = _gpu_encode_blocks(fq, text, block, enc)
+    assert res.n_records == case["n_records"]
+    assert body == want[10:]
+    back = fq.compress.Decompress(want[:10] + body)
+    assert back == O.decompress(want)
+    if not case["crlf"]:
+        assert back == text  # {A,C,G,T,N} data round-trips exactly
+
+
+def test_long_reads_and_long_headers(fq):
+    """reads far longer than a wave's piece round (64 x 16 bytes) and headers near the u16 limit"""
+    rng = np.random.default_rng(5)
+    recs = []
+    for i, L in enumerate([70000, 1, 0, 4097, 65535, 20000]):
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), L))
+        qual = bytes(rng.integers(35, 74, L, dtype=np.uint8))
+        hdr = b"@r%d " % i + b"x" * int(rng.choice([0, 10, 300, 5000, 60000]))
+        recs.append(hdr + b"\n" + seq + b"\n+" + (b"p" * (i * 37)) + b"\n" + qual + b"\n")
+    text = b"".join(recs)
+    want = O.compress(text, batch_records=4)
+    body, res = _gpu_encode_blocks(fq, text, 4, 0)
+    assert body == want[10:]
+    assert fq.compress.Decompress(want) == text
