@@ -69,3 +69,44 @@ def test_long_reads_and_long_headers(fq):
     body, res = _gpu_encode_blocks(fq, text, 4, 0)
     assert body == want[10:]
     assert fq.compress.Decompress(want) == text
+
+
+def test_corrupted_containers_are_refused_or_decoded_never_crash(fq):
+    """bit flips and truncations anywhere in a container (block header, frame headers, tree descriptions, bit streams,
+    foreign LZ payloads): the decoder must answer with an error or with some text — never hang or fault"""
+    rng = np.random.default_rng(99)
+    text = make_fastq(n_records=400, seed=5, min_len=60, max_len=140, n_frac=0.05, plus_payload=True)
+    ours = O.compress(text)
+    import struct
+    body = ours[10:]
+    hdr = list(struct.unpack("<9I", body[:36]))
+    recs, nrec = O.parse_all(text)
+    streams, _ = O.split_block(text, recs, nrec, 0)
+    pays = [O.zstd_compress(streams[k], 3) if len(streams[k]) else b"" for k in range(6)]
+    hdr[1:7] = [len(p) for p in pays]
+    foreign = ours[:10] + struct.pack("<9I", *hdr) + b"".join(pays)
+    assert fq.compress.Decompress(foreign) == text
+    n_err = n_ok = 0
+    for base in (ours, foreign):
+        for trial in range(40):
+            z = bytearray(base)
+            kind = trial % 4
+            if kind == 0:
+                z[int(rng.integers(10, len(z)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                for _ in range(8):
+                    z[int(rng.integers(10, len(z)))] = int(rng.integers(0, 256))
+            elif kind == 2:
+                z = z[: int(rng.integers(11, len(z)))]
+            else:
+                p = int(rng.integers(10, len(z) - 64))
+                z[p:p + 32] = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+            try:
+                out = fq.compress.Decompress(bytes(z))
+                n_ok += 1
+                assert isinstance(out, bytes)
+            except fq.FqzError:
+                n_err += 1
+    assert n_err > 40 and n_err + n_ok == 80
+    # the context still works afterwards
+    assert fq.compress.Decompress(ours) == text
