@@ -74,6 +74,7 @@ struct EncState {
     DevBuf E;         // u32[5][rec_cap+1]: seq, qual, hdr, plus, npos sizes -> exclusive offsets
     DevBuf rs_state;  // look-back states of k_record_scan + its ticket
     DevBuf scan_state; // look-back states of k_scan + its ticket
+    DevBuf gmap;      // chunk-group descriptors (k_group_map)
     DevBuf plans;     // BlockPlan[block_cap]
     DevBuf arena;     // seq/qual/hdr/plus/len pre-entropy streams
     DevBuf npos;      // nPos pre-entropy streams

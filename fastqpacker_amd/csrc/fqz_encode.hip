@@ -684,33 +684,34 @@ __device__ __forceinline__ void locate_chunk(const EncInfo *info, const BlockPla
     *cidx = chunk - p->chunk_base[s];
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_entropy(const EncInfo *info, const BlockPlan *plans, const uint8_t *arena, const uint8_t *npos_arena,
+// groups of up to FQZ_GROUP consecutive chunks of one stream share a Huffman table: one thread per chunk finds the
+// group leaders and appends a descriptor {first chunk id, arena offset, bytes | last << 24 | stream << 28, 0}
+__global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPlan *plans, uint4 *gmap, uint32_t group_cap)
+{
+    const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
+    if (chunk >= info->n_chunks) return;
+    uint32_t b, c;
+    int s;
+    locate_chunk(info, plans, chunk, &b, &s, &c);
+    if (c % FQZ_GROUP) return;
+    const BlockPlan *p = &plans[b];
+    const uint32_t off = c * FQZ_CHUNK;
+    const uint32_t M = p->len[s] - off < FQZ_GROUP * FQZ_CHUNK ? p->len[s] - off : FQZ_GROUP * FQZ_CHUNK;
+    const uint32_t last = off + M == p->len[s];
+    const uint32_t g = atomicAdd(&info->n_groups, 1u); // any order: groups are independent
+    if (g < group_cap) gmap[g] = make_uint4(chunk, p->a_off[s] + off, M | (last << 24) | ((uint32_t)s << 28), 0u);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_entropy(const EncInfo *info, const uint4 *gmap, const uint8_t *arena, const uint8_t *npos_arena,
                                                  uint8_t *slots, uint32_t *csize, int dbg_stop, unsigned long long *stamps)
 {
     __shared__ __attribute__((aligned(16))) EntropyLds S;
-    const uint32_t chunk = blockIdx.x;
-    if (chunk >= info->n_chunks) return;
-    const uint32_t t = threadIdx.x;
-    if (stamps) { stamps += (size_t)chunk * 16; if (t == 0) stamps[0] = __builtin_amdgcn_s_memtime(); }
-
-    if (t == 0) {
-        uint32_t b, c;
-        int s;
-        locate_chunk(info, plans, chunk, &b, &s, &c);
-        const BlockPlan *p = &plans[b];
-        if (stamps) stamps[15] = (unsigned long long)s;
-        uint32_t off = c * FQZ_CHUNK;
-        uint32_t m = p->len[s] - off < FQZ_CHUNK ? p->len[s] - off : FQZ_CHUNK;
-        S.misc[0] = p->a_off[s] + off;
-        S.misc[1] = m;
-        S.misc[2] = (off + m == p->len[s]);
-        S.misc[3] = (uint32_t)s;
-    }
-    __syncthreads();
-    const uint32_t m = S.misc[1], last = S.misc[2];
-    const uint8_t *src = (S.misc[3] == S_NPOS ? npos_arena : arena) + S.misc[0]; // 16-byte aligned
-    __syncthreads(); // misc[0..3] are reused by the encoder
-    entropy_encode_chunk(S, src, m, last, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
+    if (blockIdx.x >= info->n_groups) return;
+    const uint4 gd = gmap[blockIdx.x];
+    const uint32_t chunk = gd.x, M = gd.z & 0xFFFFFFu, last = (gd.z >> 24) & 1u, s = gd.z >> 28;
+    if (stamps) { stamps += (size_t)chunk * 16; if (threadIdx.x == 0) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[15] = (unsigned long long)s; } }
+    const uint8_t *src = (s == S_NPOS ? npos_arena : arena) + gd.y; // 16-byte aligned
+    entropy_encode_group(S, src, M, last, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
 }
 
 // N positions: u16 count + ascending u16 positions per record (compress.go:477-488, 507-512)
@@ -990,7 +991,10 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap))) return rc;
     PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
     PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, npos));
-    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
+    const uint32_t group_cap = e.chunk_cap / FQZ_GROUP + FQZ_NS * e.block_cap + 8;
+    if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
+    PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap));
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out));
@@ -1103,7 +1107,10 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     uint32_t *csize = e.csize.as<uint32_t>();
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, 0);
     hipLaunchKernelGGL(k_single_plan, dim3(1), dim3(64), 0, st, info, plans, (uint32_t)n);
-    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(chunks), dim3(256), 0, st, info, plans, d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
+    const uint32_t group_cap = chunks / FQZ_GROUP + 8;
+    if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
+    hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap);
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;
     hipLaunchKernelGGL(k_single_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_dst, cap);
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, d_dst));

@@ -266,16 +266,26 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
 }
 
 // ---------------------------------------------------------------------------------------------
-// One chunk -> one zstd block.  src is 16-byte aligned global memory holding the m chunk bytes.
-// All 256 threads call this; they return together.
+// One GROUP of up to FQZ_GROUP consecutive 16 KiB chunks of a stream -> one zstd block per chunk, all sharing ONE
+// Huffman table built from the histogram of the whole group (the first Compressed block carries the tree, the
+// others are treeless).  src is 16-byte aligned global memory holding the M group bytes; chunk k goes to
+// slot0 + k * FQZ_SLOT and its size to csize0[k].  All 256 threads call this; they return together.
 //
-// Symbol ownership (fixed by the format: 4 Huffman streams of ceil(m/4) bytes when m >= 256, else 1): wave w
-// encodes stream w, lane l the `per` consecutive symbols [l*per, (l+1)*per) of it, per <= 64, kept in sym[16].
+// The kernel is bound by the LDS pipeline (histogram atomics, code-table lookups, bit packing, the table build), so:
+//  * phase 1 loads every chunk once for the histogram, phase 2 loads it again (L2-hot) to encode it; the table
+//    build in between — a quarter of a chunk's LDS traffic — is paid once per 64 KiB;
+//  * a full chunk does not touch LDS on its way in: lane l of wave w owns the 64 consecutive bytes at 4096 w + 64 l
+//    and loads them straight from global memory (4 x 128 bit; the four loads of a wave cover the same 32 cache
+//    lines, the vector L1 merges them).  Partial chunks (the last one of a stream) have odd stream lengths and go
+//    through a staged copy in the not-yet-used output buffer.
+//
+// Symbol ownership inside a chunk (fixed by the format: 4 Huffman streams of ceil(m/4) bytes when m >= 256, else 1):
+// wave w encodes stream w, lane l the `per` consecutive symbols [l*per, (l+1)*per) of it, per <= 64, kept in sym[16].
 // ---------------------------------------------------------------------------------------------
-// dbg_stop > 0 (FQZ_DBG_STOP, timing experiments only): leave after that phase with a dummy 4-byte block
+// dbg_stop > 0 (FQZ_DBG_STOP, timing experiments only): leave after that phase with dummy 4-byte blocks
 // stamps != nullptr (FQZ_DBG_STAMPS, diagnostic runs only): lane 0 records s_memtime at every phase boundary
 #define DBG_STOP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime(); \
-                         if (dbg_stop == (k)) { if (threadIdx.x == 0) *csize_out = 4; return; } } while (0)
+                         if (dbg_stop == (k)) { if (threadIdx.x < nchunk) csize0[threadIdx.x] = 4; return; } } while (0)
 __device__ __forceinline__ uint32_t lds_load_u32_unaligned(const uint8_t *p)
 {
     uint32_t v;
@@ -283,78 +293,96 @@ __device__ __forceinline__ uint32_t lds_load_u32_unaligned(const uint8_t *p)
     return v;
 }
 
-__device__ void entropy_encode_chunk(EntropyLds &S, const uint8_t *src, const uint32_t m, const uint32_t last, uint8_t *slot, uint32_t *csize_out,
-                                     const int dbg_stop = 0, unsigned long long *stamps = nullptr)
+struct ChunkSyms { // the symbols of this lane for the chunk in flight
+    uint32_t sym[16];
+    uint32_t cnt, nstreams;
+};
+
+// every lane gets its symbols of chunk [src, src + m) (see "symbol ownership"); ends with a barrier
+__device__ __forceinline__ void load_chunk_syms(EntropyLds &S, const uint8_t *src, const uint32_t m, ChunkSyms &C)
 {
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    // ---- my symbols -> registers (see "symbol ownership").  The kernel is bound by the LDS pipeline (histogram atomics,
-    //      code table lookups, bit packing), so a full chunk does not touch LDS on its way in: lane l of wave w owns the
-    //      64 consecutive bytes at 4096 w + 64 l and loads them straight from global memory (4 x 128 bit; the four
-    //      loads of a wave cover the same 32 cache lines, the vector L1 merges them).  Partial chunks (the last one of a
-    //      stream) have odd stream lengths and go through a staged copy in the not-yet-used output buffer.
-    const uint32_t nstreams = m >= 256 ? 4 : 1;
-    const uint32_t seg = nstreams == 4 ? (m + 3) / 4 : m;
+    C.nstreams = m >= 256 ? 4 : 1;
+    if (m == FQZ_CHUNK) {
+        const uint4 *p = (const uint4 *)(src + 4096 * wave + 64 * lane);
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        C.sym[0] = a.x; C.sym[1] = a.y; C.sym[2] = a.z; C.sym[3] = a.w; C.sym[4] = b.x; C.sym[5] = b.y; C.sym[6] = b.z; C.sym[7] = b.w;
+        C.sym[8] = c.x; C.sym[9] = c.y; C.sym[10] = c.z; C.sym[11] = c.w; C.sym[12] = d.x; C.sym[13] = d.y; C.sym[14] = d.z; C.sym[15] = d.w;
+        C.cnt = 64;
+        __syncthreads();
+        return;
+    }
+    const uint32_t seg = C.nstreams == 4 ? (m + 3) / 4 : m;
     const uint32_t seg_base = wave * seg;
     uint32_t seg_len = 0;
-    if (wave < nstreams) seg_len = (wave == nstreams - 1) ? m - seg_base : seg;
+    if (wave < C.nstreams) seg_len = (wave == C.nstreams - 1) ? m - seg_base : seg;
     const uint32_t per = ((seg_len + 63) / 64 + 3) & ~3u; // symbols per lane, a multiple of 4, <= 64
     uint32_t sym_a = lane * per, sym_b = sym_a + per;
     if (sym_a > seg_len) sym_a = seg_len;
     if (sym_b > seg_len) sym_b = seg_len;
-    const uint32_t cnt = sym_b - sym_a;
-    uint32_t sym[16];
-    S.ctab[t] = 0;
-    if (m == FQZ_CHUNK) {
-        const uint4 *p = (const uint4 *)(src + 4096 * wave + 64 * lane);
-        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-        sym[0] = a.x; sym[1] = a.y; sym[2] = a.z; sym[3] = a.w; sym[4] = b.x; sym[5] = b.y; sym[6] = b.z; sym[7] = b.w;
-        sym[8] = c.x; sym[9] = c.y; sym[10] = c.z; sym[11] = c.w; sym[12] = d.x; sym[13] = d.y; sym[14] = d.z; sym[15] = d.w;
-        __syncthreads(); // the zeroed histogram
-    } else {
-        uint4 v[4];
+    C.cnt = sym_b - sym_a;
+    uint4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { // all four loads in flight before the first use; bytes at or beyond m read as 0
-            const uint32_t off = (t + 256 * q) * 16;
-            const uint32_t have = off < m ? (m - off < 16 ? m - off : 16) : 0;
-            v[q] = make_uint4(0, 0, 0, 0);
-            if (have == 16) v[q] = *(const uint4 *)(src + off);
-            else if (have) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint32_t k = 0; k < have; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
-                v[q] = make_uint4(w[0], w[1], w[2], w[3]);
-            }
+    for (int q = 0; q < 4; q++) { // all four loads in flight before the first use; bytes at or beyond m read as 0
+        const uint32_t off = (t + 256 * q) * 16;
+        const uint32_t have = off < m ? (m - off < 16 ? m - off : 16) : 0;
+        v[q] = make_uint4(0, 0, 0, 0);
+        if (have == 16) v[q] = *(const uint4 *)(src + off);
+        else if (have) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint32_t k = 0; k < have; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
+            v[q] = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        if (t < OUT_WORDS - FQZ_CHUNK / 4) S.out[FQZ_CHUNK / 4 + t] = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) *(uint4 *)&S.out[(t + 256 * q) * 4] = v[q];
-        __syncthreads();
-        const uint8_t *mine = (const uint8_t *)S.out + seg_base + sym_a;
-#pragma unroll
-        for (int d = 0; d < 16; d++) sym[d] = 4u * d < cnt ? lds_load_u32_unaligned(mine + 4 * d) : 0u;
     }
-    // ---- byte histogram.  Skewed data (quality deltas are ~90 % zeros) would serialise LDS atomics on one bin, so every
-    //      wave first peels off its dominant byte: the candidate is the first byte the wave sees, matches are counted with
-    //      SWAR compares in registers and added once per wave.
-    {
-        const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sym[0] & 0xFF)); // wave-uniform candidate byte
+    if (t < OUT_WORDS - FQZ_CHUNK / 4) S.out[FQZ_CHUNK / 4 + t] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) *(uint4 *)&S.out[(t + 256 * q) * 4] = v[q];
+    __syncthreads();
+    const uint8_t *mine = (const uint8_t *)S.out + seg_base + sym_a;
+#pragma unroll
+    for (int d = 0; d < 16; d++) C.sym[d] = 4u * d < C.cnt ? lds_load_u32_unaligned(mine + 4 * d) : 0u;
+    __syncthreads(); // the staged copy may be overwritten
+}
+
+__device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const uint32_t M, const uint32_t last, uint8_t *slot0, uint32_t *csize0,
+                                     const int dbg_stop = 0, unsigned long long *stamps = nullptr)
+{
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const uint32_t nchunk = (M + FQZ_CHUNK - 1) / FQZ_CHUNK;
+    const uint32_t m = M; // the table-build code below speaks of "m": the byte count the histogram covers
+    // ---- phase 1: histogram of the whole group; per chunk, whether all its bytes are equal (RLE block).
+    //      Skewed data (quality deltas are ~90 % zeros) would serialise LDS atomics on one bin, so every wave first peels
+    //      off its dominant byte: the candidate is the first byte the wave sees, matches are counted with SWAR compares
+    //      in registers and added once per wave.
+    S.ctab[t] = 0;
+    uint32_t same_mask = 0; // bit k: chunk k is one repeated byte
+#pragma clang loop unroll(disable)
+    for (uint32_t k = 0; k < nchunk; k++) {
+        const uint32_t mk = M - k * FQZ_CHUNK < FQZ_CHUNK ? M - k * FQZ_CHUNK : FQZ_CHUNK;
+        const uint8_t *csrc = src + (size_t)k * FQZ_CHUNK;
+        ChunkSyms C;
+        load_chunk_syms(S, csrc, mk, C);
+        const uint32_t b0 = (uint32_t)csrc[0] * 0x01010101u;
+        const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(C.sym[0] & 0xFF)); // wave-uniform candidate byte
         const uint32_t cand4 = cand * 0x01010101u;
-        uint32_t n_cand = 0;
+        uint32_t n_cand = 0, differs = 0;
 #pragma unroll
         for (int d = 0; d < 16; d++) {
-            const uint32_t valid = cnt >= 4u * d + 4 ? 0x80808080u : (cnt > 4u * d ? (0x80808080u >> (8 * (4 * d + 4 - cnt))) : 0u);
-            const uint32_t eq = zero_bytes(sym[d] ^ cand4) & valid;
+            const uint32_t valid = C.cnt >= 4u * d + 4 ? 0x80808080u : (C.cnt > 4u * d ? (0x80808080u >> (8 * (4 * d + 4 - C.cnt))) : 0u);
+            const uint32_t eq = zero_bytes(C.sym[d] ^ cand4) & valid;
+            differs |= ~zero_bytes(C.sym[d] ^ b0) & valid;
             n_cand += __popc(eq);
             uint32_t other = valid & ~eq; // 0x80 per byte that still needs an atomic
             while (other) {
                 int bit = __ffs(other) - 1; // 7, 15, 23 or 31
                 other &= other - 1;
-                atomicAdd(&S.ctab[(sym[d] >> (bit - 7)) & 0xFF], 1u);
+                atomicAdd(&S.ctab[(C.sym[d] >> (bit - 7)) & 0xFF], 1u);
             }
         }
         n_cand = wave_sum(n_cand);
         if (lane == 0 && n_cand) atomicAdd(&S.ctab[cand], n_cand);
+        if (!__syncthreads_or(differs != 0)) same_mask |= 1u << k;
     }
-    __syncthreads(); // the staging copy is dead, the histogram complete
     DBG_STOP(1);
     uint32_t *const keys = lds_keys(S), *const sorted = lds_sorted(S);
     // S.misc: 4 n_active, 5 mode (0 raw, 1 rle, 2 huffman), 6 tree size, 7 max bits, 8..11 per-wave scratch / stream bits,
@@ -363,7 +391,6 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint8_t *src, const ui
     {
         uint32_t c = S.ctab[t];
         keys[t] = c ? ((c << 8) | t) : 0u;
-        if (c) S.misc[30] = t; // the byte of an RLE block
         unsigned long long act = __ballot(c != 0);
         uint32_t sq = wave_sum(c * c); // c <= 16384, the sum of squares <= 2^28
         if (lane == 0) { S.misc[8 + wave] = (uint32_t)__popcll(act); S.misc[16 + wave] = sq; }
@@ -570,78 +597,99 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint8_t *src, const ui
             }
             S.ctab[t] = code | (nb << 16);
         }
-        // keep the tree description in registers while the staging buffer is cleared
-        uint8_t tree_byte = t < tree_size ? sc->tree[t] : 0;
-        __syncthreads();
-        for (uint32_t i = t; i < OUT_WORDS; i += 256) S.out[i] = 0;
-        __syncthreads();
-
-        DBG_STOP(6);
-        // ---- pass 1: bits per lane, per stream (wave w encodes stream w)
-        uint32_t my_bits = 0;
+    }
+    // the tree description stays in a register: the output buffer is reused by every chunk below
+    const uint8_t tree_byte = (mode == 2 && t < tree_size) ? sc->tree[t] : 0;
+    __syncthreads();
+    DBG_STOP(6);
+    // ---- phase 2: one zstd block per chunk
+    uint32_t tree_sent = 0;
+#pragma clang loop unroll(disable)
+    for (uint32_t k = 0; k < nchunk; k++) {
+        const uint32_t mk = M - k * FQZ_CHUNK < FQZ_CHUNK ? M - k * FQZ_CHUNK : FQZ_CHUNK;
+        const uint8_t *csrc = src + (size_t)k * FQZ_CHUNK;
+        uint8_t *slot = slot0 + (size_t)k * FQZ_SLOT;
+        const uint32_t lastblk = (last && k + 1 == nchunk) ? 1u : 0u;
+        if (same_mask & (1u << k)) { // RLE block: 3-byte header + the byte
+            if (t == 0) {
+                const uint32_t bh = lastblk | (1u << 1) | (mk << 3);
+                *(uint32_t *)slot = (bh & 0xFFFFFF) | ((uint32_t)csrc[0] << 24);
+                csize0[k] = 4;
+            }
+            continue;
+        }
+        uint32_t cmode = mode; // 2 = Huffman with the group table, anything else = raw
+        if (cmode == 2) {
+            ChunkSyms C;
+            load_chunk_syms(S, csrc, mk, C);
+            for (uint32_t i = t; i < OUT_WORDS; i += 256) S.out[i] = 0;
+            // ---- pass 1: bits per lane, per stream (wave w encodes stream w)
+            uint32_t my_bits = 0;
 #pragma unroll
-        for (int d = 0; d < 16; d++) {
-            if (4u * d + 4 <= cnt) {
-                my_bits += (S.ctab[sym[d] & 0xFF] >> 16) + (S.ctab[(sym[d] >> 8) & 0xFF] >> 16) + (S.ctab[(sym[d] >> 16) & 0xFF] >> 16) +
-                           (S.ctab[sym[d] >> 24] >> 16);
-            } else if (4u * d < cnt) {
-                for (uint32_t z = 0; z < cnt - 4u * d; z++) my_bits += S.ctab[(sym[d] >> (8 * z)) & 0xFF] >> 16;
-            }
-        }
-        uint32_t incl = wave_incl_scan(my_bits);
-        uint32_t tot_bits = __shfl(incl, 63, WAVE);
-        uint32_t bit_off = tot_bits - incl; // bits of all higher lanes = symbols written before mine
-        if (lane == 0) S.misc[8 + wave] = tot_bits;
-        __syncthreads();
-        DBG_STOP(7);
-        // ---- sizes, raw fallback, headers (one lane; before any atomicOr touches those words)
-        if (t == 0) {
-            uint32_t ssz[4] = {0, 0, 0, 0}, total_streams = 0;
-            for (uint32_t k = 0; k < nstreams; k++) { ssz[k] = (S.misc[8 + k] >> 3) + 1; total_streams += ssz[k]; }
-            uint32_t lit_csize = tree_size + (nstreams == 4 ? 6 : 0) + total_streams;
-            uint32_t lh = m < 1024 ? 3 : (m < 16384 ? 4 : 5);
-            uint32_t content = lh + lit_csize + 1;
-            if (content >= m) S.misc[5] = 0;
-            else {
-                S.misc[5] = 2;
-                uint8_t *o = (uint8_t *)S.out;
-                uint32_t bh = (last & 1) | (2u << 1) | (content << 3);
-                o[0] = (uint8_t)bh; o[1] = (uint8_t)(bh >> 8); o[2] = (uint8_t)(bh >> 16);
-                if (lh == 3) {
-                    uint32_t v = 2u | ((nstreams == 4 ? 1u : 0u) << 2) | (m << 4) | (lit_csize << 14);
-                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16);
-                } else if (lh == 4) {
-                    uint32_t v = 2u | (2u << 2) | (m << 4) | (lit_csize << 18);
-                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
-                } else {
-                    uint32_t v = 2u | (3u << 2) | (m << 4) | (lit_csize << 22);
-                    o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
-                    o[7] = (uint8_t)(lit_csize >> 10);
+            for (int d = 0; d < 16; d++) {
+                if (4u * d + 4 <= C.cnt) {
+                    my_bits += (S.ctab[C.sym[d] & 0xFF] >> 16) + (S.ctab[(C.sym[d] >> 8) & 0xFF] >> 16) + (S.ctab[(C.sym[d] >> 16) & 0xFF] >> 16) +
+                               (S.ctab[C.sym[d] >> 24] >> 16);
+                } else if (4u * d < C.cnt) {
+                    for (uint32_t z = 0; z < C.cnt - 4u * d; z++) my_bits += S.ctab[(C.sym[d] >> (8 * z)) & 0xFF] >> 16;
                 }
-                uint32_t pos = 3 + lh + tree_size;
-                if (nstreams == 4) {
-                    for (int k = 0; k < 3; k++) { o[pos + 2 * k] = (uint8_t)ssz[k]; o[pos + 2 * k + 1] = (uint8_t)(ssz[k] >> 8); }
-                    pos += 6;
-                }
-                for (uint32_t k = 0; k < 4; k++) { S.misc[8 + k] = pos; pos += ssz[k]; } // stream start bytes
-                o[pos] = 0;                                                                // Number_of_Sequences = 0
-                S.misc[12] = pos + 1;
-                S.misc[14] = 3 + lh; // tree offset
             }
-        }
-        __syncthreads();
-        mode = S.misc[5];
-        if (mode == 2) {
-            uint8_t *o = (uint8_t *)S.out;
-            if (t < tree_size) o[S.misc[14] + t] = tree_byte;
+            const uint32_t incl = wave_incl_scan(my_bits);
+            const uint32_t tot_bits = __shfl(incl, 63, WAVE);
+            const uint32_t bit_off = tot_bits - incl; // bits of all higher lanes = symbols written before mine
+            if (lane == 0) S.misc[8 + wave] = tot_bits;
             __syncthreads();
-            // ---- pass 2: symbols last-to-first, LSB-first bit packing (HUF_compress1X order)
-            if (wave < nstreams) {
-                uint32_t P0 = 8 * S.misc[8 + wave] + bit_off;
-                uint32_t word = P0 >> 5;
-                uint32_t fill = P0 & 31;
-                unsigned long long acc = 0;
-                // two symbols per step (<= 22 new bits on top of < 32 pending fit the 64-bit accumulator)
+            // ---- sizes, raw fallback, headers (one lane; before any atomicOr touches those words)
+            const uint32_t tsz = tree_sent ? 0u : tree_size;
+            if (t == 0) {
+                const uint32_t nstreams = C.nstreams;
+                uint32_t ssz[4] = {0, 0, 0, 0}, total_streams = 0;
+                for (uint32_t q = 0; q < nstreams; q++) { ssz[q] = (S.misc[8 + q] >> 3) + 1; total_streams += ssz[q]; }
+                const uint32_t lit_csize = tsz + (nstreams == 4 ? 6 : 0) + total_streams;
+                const uint32_t lh = mk < 1024 ? 3 : (mk < 16384 ? 4 : 5);
+                const uint32_t content = lh + lit_csize + 1;
+                if (content >= mk) S.misc[5] = 0;
+                else {
+                    S.misc[5] = 2;
+                    uint8_t *o = (uint8_t *)S.out;
+                    const uint32_t bh = lastblk | (2u << 1) | (content << 3);
+                    const uint32_t lt = tree_sent ? 3u : 2u; // treeless once the group's table has been sent
+                    o[0] = (uint8_t)bh; o[1] = (uint8_t)(bh >> 8); o[2] = (uint8_t)(bh >> 16);
+                    if (lh == 3) {
+                        uint32_t v = lt | ((nstreams == 4 ? 1u : 0u) << 2) | (mk << 4) | (lit_csize << 14);
+                        o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16);
+                    } else if (lh == 4) {
+                        uint32_t v = lt | (2u << 2) | (mk << 4) | (lit_csize << 18);
+                        o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
+                    } else {
+                        uint32_t v = lt | (3u << 2) | (mk << 4) | (lit_csize << 22);
+                        o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
+                        o[7] = (uint8_t)(lit_csize >> 10);
+                    }
+                    uint32_t pos = 3 + lh + tsz;
+                    if (nstreams == 4) {
+                        for (int q = 0; q < 3; q++) { o[pos + 2 * q] = (uint8_t)ssz[q]; o[pos + 2 * q + 1] = (uint8_t)(ssz[q] >> 8); }
+                        pos += 6;
+                    }
+                    for (uint32_t q = 0; q < 4; q++) { S.misc[8 + q] = pos; pos += ssz[q]; } // stream start bytes
+                    o[pos] = 0;                                                                // Number_of_Sequences = 0
+                    S.misc[12] = pos + 1;
+                    S.misc[14] = 3 + lh; // tree offset
+                }
+            }
+            __syncthreads();
+            cmode = S.misc[5];
+            if (cmode == 2) {
+                uint8_t *o = (uint8_t *)S.out;
+                if (t < tsz) o[S.misc[14] + t] = tree_byte;
+                __syncthreads();
+                // ---- pass 2: symbols last-to-first, LSB-first bit packing (HUF_compress1X order)
+                if (wave < C.nstreams) {
+                    uint32_t P0 = 8 * S.misc[8 + wave] + bit_off;
+                    uint32_t word = P0 >> 5;
+                    uint32_t fill = P0 & 31;
+                    unsigned long long acc = 0;
+                    // two symbols per step (<= 22 new bits on top of < 32 pending fit the 64-bit accumulator)
 #define PUT2(s1, s2) do { uint32_t e1 = S.ctab[(s1)], e2 = S.ctab[(s2)];                         \
                           acc |= (unsigned long long)(e1 & 0xFFFF) << fill; fill += e1 >> 16;  \
                           acc |= (unsigned long long)(e2 & 0xFFFF) << fill; fill += e2 >> 16;  \
@@ -653,47 +701,42 @@ __device__ void entropy_encode_chunk(EntropyLds &S, const uint8_t *src, const ui
                       atomicOr(&S.out[word], (uint32_t)acc);                                   \
                       uint32_t adv = fill >> 5; acc >>= (adv << 5); word += adv; fill &= 31; } while (0)
 #pragma unroll
-                for (int d = 15; d >= 0; d--) {
-                    if (4u * d + 4 <= cnt) {
-                        PUT2(sym[d] >> 24, (sym[d] >> 16) & 0xFF);
-                        PUT2((sym[d] >> 8) & 0xFF, sym[d] & 0xFF);
-                    } else if (4u * d < cnt) {
-                        for (int z = (int)(cnt - 4u * d) - 1; z >= 0; z--) PUT1((sym[d] >> (8 * z)) & 0xFF);
+                    for (int d = 15; d >= 0; d--) {
+                        if (4u * d + 4 <= C.cnt) {
+                            PUT2(C.sym[d] >> 24, (C.sym[d] >> 16) & 0xFF);
+                            PUT2((C.sym[d] >> 8) & 0xFF, C.sym[d] & 0xFF);
+                        } else if (4u * d < C.cnt) {
+                            for (int z = (int)(C.cnt - 4u * d) - 1; z >= 0; z--) PUT1((C.sym[d] >> (8 * z)) & 0xFF);
+                        }
                     }
-                }
 #undef PUT2
 #undef PUT1
-                if (lane == 0) { acc |= 1ull << fill; fill += 1; } // end mark above the first symbol's code
-                if (fill) atomicOr(&S.out[word], (uint32_t)acc);
-                if (fill > 32) atomicOr(&S.out[word + 1], (uint32_t)(acc >> 32));
+                    if (lane == 0) { acc |= 1ull << fill; fill += 1; } // end mark above the first symbol's code
+                    if (fill) atomicOr(&S.out[word], (uint32_t)acc);
+                    if (fill > 32) atomicOr(&S.out[word + 1], (uint32_t)(acc >> 32));
+                }
+                __syncthreads();
+                const uint32_t total = S.misc[12];
+                uint32_t *slot32 = (uint32_t *)slot;
+                for (uint32_t i = t; i < (total + 3) / 4; i += 256) slot32[i] = S.out[i];
+                if (t == 0) csize0[k] = total;
+                tree_sent = 1;
+                __syncthreads(); // S.out and S.misc are reused by the next chunk
+                continue;
             }
             __syncthreads();
-            DBG_STOP(8);
-            uint32_t total = S.misc[12];
-            uint32_t *slot32 = (uint32_t *)slot;
-            for (uint32_t i = t; i < (total + 3) / 4; i += 256) slot32[i] = S.out[i];
-            if (t == 0) *csize_out = total;
-            DBG_STOP(9);
-            return;
+        }
+        // raw block: 3-byte header + the mk bytes, copied from global memory (L2-hot) with 128-bit accesses
+        {
+            const uint32_t bh = lastblk | (0u << 1) | (mk << 3);
+            if (t == 0) { slot[0] = (uint8_t)bh; slot[1] = (uint8_t)(bh >> 8); slot[2] = (uint8_t)(bh >> 16); }
+            for (uint32_t off = t * 16; off < mk; off += 256 * 16) {
+                if (off + 16 <= mk) store_u128_unaligned(slot + 3 + off, *(const uint4 *)(csrc + off));
+                else
+                    for (uint32_t q = off; q < mk; q++) slot[3 + q] = csrc[q];
+            }
+            if (t == 0) csize0[k] = 3 + mk;
         }
     }
-    if (mode == 1) { // RLE block: 3-byte header + the byte
-        if (t == 0) {
-            uint32_t bh = (last & 1) | (1u << 1) | (m << 3);
-            *(uint32_t *)slot = (bh & 0xFFFFFF) | (S.misc[30] << 24);
-            *csize_out = 4;
-        }
-        return;
-    }
-    // raw block: 3-byte header + the m bytes, copied from global memory (L2-hot) with 128-bit accesses
-    {
-        const uint32_t bh = (last & 1) | (0u << 1) | (m << 3);
-        if (t == 0) { slot[0] = (uint8_t)bh; slot[1] = (uint8_t)(bh >> 8); slot[2] = (uint8_t)(bh >> 16); }
-        for (uint32_t off = t * 16; off < m; off += 256 * 16) {
-            if (off + 16 <= m) store_u128_unaligned(slot + 3 + off, *(const uint4 *)(src + off));
-            else
-                for (uint32_t k = off; k < m; k++) slot[3 + k] = src[k];
-        }
-        if (t == 0) *csize_out = 3 + m;
-    }
+    DBG_STOP(9);
 }

@@ -8,6 +8,7 @@
 
 #define FQZ_CHUNK 16384u               // pre-entropy bytes per zstd block (== FQZ_ENTROPY_CHUNK)
 #define FQZ_SLOT (FQZ_CHUNK + 64u)     // per-chunk staging slot in HBM (raw worst case 3+16384, padded for aligned reads)
+#define FQZ_GROUP 4u                   // chunks that share one Huffman table (one workgroup of k_entropy)
 #define FQZ_TILE 4096u                 // text bytes per line-index workgroup
 #define FQZ_NS 6
 enum { S_SEQ = 0, S_QUAL = 1, S_HDR = 2, S_PLUS = 3, S_NPOS = 4, S_LEN = 5 };
@@ -27,6 +28,7 @@ struct EncInfo {
     uint32_t qual_off;      // 33 or 64
     uint32_t n_chunks;      // all chunks: ids [0, n_main) = seq/qual/headers/plus/lengths, [n_main, n_chunks) = nPos
     uint32_t n_main;
+    uint32_t n_groups;      // chunk groups (k_group_map)
     uint32_t arena_used;    // bytes of the main arena in use
     uint32_t npos_used;
     unsigned long long error_key; // (record << 8 | check order << 4 | code index), min wins

@@ -298,75 +298,99 @@ static size_t huf_stream(const uint8_t *src, size_t n, const uint16_t *code, con
     return (size_t)(bw_close(&bw) - dst);
 }
 
-size_t fqzo_encode_chunk(const uint8_t *src, size_t m, int last, uint8_t *dst)
+/* One GROUP of up to FQZO_GROUP consecutive 16 KiB chunks = up to 64 KiB of a stream.  FQZ-H1 builds ONE Huffman
+ * table per group, from the histogram of the whole group: the first Compressed block of the group carries the tree
+ * description, the others are "treeless" (Literals_Block_Type 3, RFC 8878 3.1.1.3.1.1: reuse the previous table).
+ * On the GPU the table build (sort, Huffman merge, FSE weight coding) is a quarter of the LDS traffic of a chunk; a
+ * group pays it once for four blocks, and the decoder builds four times fewer tables. */
+size_t fqzo_encode_group(const uint8_t *src, size_t M, int last, uint8_t *dst)
 {
     uint32_t count[256] = {0};
-    for (size_t i = 0; i < m; i++) count[src[i]]++;
-    if (count[src[0]] == m) { /* RLE block */
-        put_block_header(dst, last, 1, (uint32_t)m);
-        dst[3] = src[0];
-        return 4;
-    }
-    if (m < 64) return raw_block(src, m, last, dst);
-    {   /* near-flat histogram: collision entropy -log2(sum p^2) >= log2(230) = 7.85 bits bounds the Shannon entropy
-         * from below, so a Huffman table could save < 2 %: store raw (this is what 2-bit packed bases look like) */
+    for (size_t i = 0; i < M; i++) count[src[i]]++;
+    int huff = 1;
+    if (count[src[0]] == M) huff = 0;          /* one symbol: every chunk is an RLE block */
+    else if (M < 64) huff = 0;
+    else {   /* near-flat histogram: collision entropy -log2(sum p^2) >= log2(230) = 7.85 bits bounds the Shannon entropy
+              * from below, so a Huffman table could save < 2 %: store raw (this is what 2-bit packed bases look like) */
         uint64_t sq = 0;
         for (int s = 0; s < 256; s++) sq += (uint64_t)count[s] * count[s];
-        if (sq * 230 <= (uint64_t)m * m) return raw_block(src, m, last, dst);
+        if (sq * 230 <= (uint64_t)M * M) huff = 0;
     }
-
     uint8_t nbits[256];
     uint16_t code[256];
-    int max_bits = fqzo_huf_code_lengths(count, nbits);
     uint8_t tree[260];
-    size_t tree_size = fqzo_huf_write_tree(nbits, max_bits, tree);
-    if (!tree_size) return raw_block(src, m, last, dst);
-    fqzo_huf_codes(nbits, max_bits, code);
-
-    int nstreams = m >= 256 ? 4 : 1;
-    size_t seg = nstreams == 4 ? (m + 3) / 4 : m;
-    size_t ssize[4] = {0, 0, 0, 0}, streams_total = 0;
-    for (int k = 0; k < nstreams; k++) {
-        size_t a = (size_t)k * seg, b = (k == nstreams - 1) ? m : a + seg;
-        uint64_t bits = 0;
-        for (size_t i = a; i < b; i++) bits += nbits[src[i]];
-        ssize[k] = (size_t)(bits >> 3) + 1;
-        streams_total += ssize[k];
+    size_t tree_size = 0;
+    if (huff) {
+        int max_bits = fqzo_huf_code_lengths(count, nbits);
+        tree_size = fqzo_huf_write_tree(nbits, max_bits, tree);
+        if (!tree_size) huff = 0;
+        else fqzo_huf_codes(nbits, max_bits, code);
     }
-    size_t lit_csize = tree_size + (nstreams == 4 ? 6 : 0) + streams_total;
-    size_t lh = m < 1024 ? 3 : (m < 16384 ? 4 : 5);
-    size_t content = lh + lit_csize + 1;
-    if (content >= m) return raw_block(src, m, last, dst);
-
-    put_block_header(dst, last, 2, (uint32_t)content);
-    uint8_t *op = dst + 3;
-    if (lh == 3) {
-        uint32_t v = 2u | ((nstreams == 4 ? 1u : 0u) << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 14);
-        op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16);
-    } else if (lh == 4) {
-        uint32_t v = 2u | (2u << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 18);
-        op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); op[3] = (uint8_t)(v >> 24);
-    } else {
-        uint32_t v = 2u | (3u << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 22);
-        op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); op[3] = (uint8_t)(v >> 24);
-        op[4] = (uint8_t)(lit_csize >> 10);
+    int tree_sent = 0;
+    uint8_t *out = dst;
+    for (size_t off = 0; off < M; off += FQZO_CHUNK) {
+        const size_t m = M - off < FQZO_CHUNK ? M - off : FQZO_CHUNK;
+        const uint8_t *c = src + off;
+        const int lastblk = last && off + m == M;
+        int same = 1;
+        for (size_t i = 1; i < m; i++) if (c[i] != c[0]) { same = 0; break; }
+        if (same) { /* RLE block */
+            put_block_header(out, lastblk, 1, (uint32_t)m);
+            out[3] = c[0];
+            out += 4;
+            continue;
+        }
+        if (!huff) { out += raw_block(c, m, lastblk, out); continue; }
+        int nstreams = m >= 256 ? 4 : 1;
+        size_t seg = nstreams == 4 ? (m + 3) / 4 : m;
+        size_t ssize[4] = {0, 0, 0, 0}, streams_total = 0;
+        for (int k = 0; k < nstreams; k++) {
+            size_t a = (size_t)k * seg, b = (k == nstreams - 1) ? m : a + seg;
+            uint64_t bits = 0;
+            for (size_t i = a; i < b; i++) bits += nbits[c[i]];
+            ssize[k] = (size_t)(bits >> 3) + 1;
+            streams_total += ssize[k];
+        }
+        const size_t tsz = tree_sent ? 0 : tree_size;
+        size_t lit_csize = tsz + (nstreams == 4 ? 6 : 0) + streams_total;
+        size_t lh = m < 1024 ? 3 : (m < 16384 ? 4 : 5);
+        size_t content = lh + lit_csize + 1;
+        if (content >= m) { out += raw_block(c, m, lastblk, out); continue; }
+        const uint32_t lt = tree_sent ? 3u : 2u; /* treeless once the group's table has been sent */
+        put_block_header(out, lastblk, 2, (uint32_t)content);
+        uint8_t *op = out + 3;
+        if (lh == 3) {
+            uint32_t v = lt | ((nstreams == 4 ? 1u : 0u) << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 14);
+            op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16);
+        } else if (lh == 4) {
+            uint32_t v = lt | (2u << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 18);
+            op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); op[3] = (uint8_t)(v >> 24);
+        } else {
+            uint32_t v = lt | (3u << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 22);
+            op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); op[3] = (uint8_t)(v >> 24);
+            op[4] = (uint8_t)(lit_csize >> 10);
+        }
+        op += lh;
+        memcpy(op, tree, tsz);
+        op += tsz;
+        tree_sent = 1;
+        if (nstreams == 4) {
+            for (int k = 0; k < 3; k++) { op[2 * k] = (uint8_t)ssize[k]; op[2 * k + 1] = (uint8_t)(ssize[k] >> 8); }
+            op += 6;
+        }
+        for (int k = 0; k < nstreams; k++) {
+            size_t a = (size_t)k * seg, b = (k == nstreams - 1) ? m : a + seg;
+            (void)huf_stream(c + a, b - a, code, nbits, op);
+            op += ssize[k];
+        }
+        *op++ = 0; /* Number_of_Sequences = 0 */
+        out = op;
     }
-    op += lh;
-    memcpy(op, tree, tree_size);
-    op += tree_size;
-    if (nstreams == 4) {
-        for (int k = 0; k < 3; k++) { op[2 * k] = (uint8_t)ssize[k]; op[2 * k + 1] = (uint8_t)(ssize[k] >> 8); }
-        op += 6;
-    }
-    for (int k = 0; k < nstreams; k++) {
-        size_t a = (size_t)k * seg, b = (k == nstreams - 1) ? m : a + seg;
-        size_t w = huf_stream(src + a, b - a, code, nbits, op);
-        (void)w;
-        op += ssize[k];
-    }
-    *op++ = 0; /* Number_of_Sequences = 0 */
-    return (size_t)(op - dst);
+    return (size_t)(out - dst);
 }
+
+/* a single chunk = a group of one */
+size_t fqzo_encode_chunk(const uint8_t *src, size_t m, int last, uint8_t *dst) { return fqzo_encode_group(src, m, last, dst); }
 
 /* ===================================================================== */
 /* frame                                                                  */
@@ -388,9 +412,10 @@ size_t fqzo_entropy_encode(const uint8_t *src, size_t n, uint8_t *dst)
     op[5] = 0x38; /* window 128 KiB */
     op[6] = (uint8_t)n; op[7] = (uint8_t)(n >> 8); op[8] = (uint8_t)(n >> 16); op[9] = (uint8_t)(n >> 24);
     op += 10;
-    for (size_t off = 0; off < n; off += FQZO_CHUNK) {
-        size_t m = n - off < FQZO_CHUNK ? n - off : FQZO_CHUNK;
-        op += fqzo_encode_chunk(src + off, m, off + m == n, op);
+    const size_t G = (size_t)FQZO_GROUP * FQZO_CHUNK;
+    for (size_t off = 0; off < n; off += G) {
+        size_t M = n - off < G ? n - off : G;
+        op += fqzo_encode_group(src + off, M, off + M == n, op);
     }
     return (size_t)(op - dst);
 }
@@ -595,7 +620,10 @@ static int huf_decode_stream(const uint8_t *src, size_t n, const hdec *dt, int t
 }
 
 /* literals section of a Compressed block; block must regenerate exactly the literals */
-static long decode_compressed_block(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
+/* the Huffman table of the previous Compressed literals of the frame, for treeless blocks */
+typedef struct { hdec dt[4096]; int table_log; int valid; } huf_state;
+
+static long decode_compressed_block(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, huf_state *hs)
 {
     if (n < 2) return FQZO_E_ENTROPY;
     int type = src[0] & 3, fmt = (src[0] >> 2) & 3;
@@ -615,7 +643,7 @@ static long decode_compressed_block(const uint8_t *src, size_t n, uint8_t *dst, 
             memset(dst, src[lh], regen);
             csize = 1;
         }
-    } else if (type == 2) {
+    } else { /* Compressed (2) or treeless (3): same size fields */
         if (fmt <= 1) {
             if (n < 3) return FQZO_E_ENTROPY;
             uint32_t v = src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16);
@@ -632,10 +660,14 @@ static long decode_compressed_block(const uint8_t *src, size_t n, uint8_t *dst, 
         if (regen > cap) return FQZO_E_DST_SMALL;
         if (lh + csize + 1 > n) return FQZO_E_ENTROPY;
         const uint8_t *ip = src + lh;
-        hdec dt[4096];
-        int table_log;
-        long used = huf_read_table(ip, csize, dt, &table_log);
-        if (used < 0) return FQZO_E_ENTROPY;
+        long used = 0;
+        if (type == 2) {
+            used = huf_read_table(ip, csize, hs->dt, &hs->table_log);
+            if (used < 0) return FQZO_E_ENTROPY;
+            hs->valid = 1;
+        } else if (!hs->valid) return FQZO_E_ENTROPY; /* treeless without a previous table */
+        const hdec *dt = hs->dt;
+        const int table_log = hs->table_log;
         ip += used;
         size_t rem = csize - (size_t)used;
         if (nstreams == 1) {
@@ -653,8 +685,6 @@ static long decode_compressed_block(const uint8_t *src, size_t n, uint8_t *dst, 
             if (huf_decode_stream(p + s1 + s2, s3, dt, table_log, dst + 2 * seg, seg) < 0) return FQZO_E_ENTROPY;
             if (huf_decode_stream(p + s1 + s2 + s3, s4, dt, table_log, dst + 3 * seg, regen - 3 * seg) < 0) return FQZO_E_ENTROPY;
         }
-    } else {
-        return FQZO_E_ENTROPY; /* treeless literals: never emitted by us */
     }
     /* sequences section: must say 0 sequences and end the block */
     if (lh + csize + 1 != n || src[lh + csize] != 0) return FQZO_E_ENTROPY;
@@ -703,30 +733,35 @@ long fqzo_entropy_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
         if (parse_frame_header(src + ip, n - ip, &h, &fcs, &ck) < 0) return FQZO_E_ENTROPY;
         ip += h;
         size_t frame_start = out;
+        huf_state *hs = (huf_state *)calloc(1, sizeof(huf_state));
+        if (!hs) return FQZO_E_ENTROPY;
+        long err = 0;
         for (;;) {
-            if (ip + 3 > n) return FQZO_E_ENTROPY;
+            if (ip + 3 > n) { err = FQZO_E_ENTROPY; break; }
             uint32_t bh = src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16);
             ip += 3;
             int last = bh & 1, type = (bh >> 1) & 3;
             size_t bs = bh >> 3;
             if (type == 0) {
-                if (ip + bs > n) return FQZO_E_ENTROPY;
-                if (out + bs > cap) return FQZO_E_DST_SMALL;
+                if (ip + bs > n) { err = FQZO_E_ENTROPY; break; }
+                if (out + bs > cap) { err = FQZO_E_DST_SMALL; break; }
                 memcpy(dst + out, src + ip, bs);
                 ip += bs; out += bs;
             } else if (type == 1) {
-                if (ip + 1 > n) return FQZO_E_ENTROPY;
-                if (out + bs > cap) return FQZO_E_DST_SMALL;
+                if (ip + 1 > n) { err = FQZO_E_ENTROPY; break; }
+                if (out + bs > cap) { err = FQZO_E_DST_SMALL; break; }
                 memset(dst + out, src[ip], bs);
                 ip += 1; out += bs;
             } else if (type == 2) {
-                if (ip + bs > n || bs > 128 * 1024) return FQZO_E_ENTROPY;
-                long r = decode_compressed_block(src + ip, bs, dst + out, cap - out);
-                if (r < 0) return r;
+                if (ip + bs > n || bs > 128 * 1024) { err = FQZO_E_ENTROPY; break; }
+                long r = decode_compressed_block(src + ip, bs, dst + out, cap - out, hs);
+                if (r < 0) { err = r; break; }
                 ip += bs; out += (size_t)r;
-            } else return FQZO_E_ENTROPY;
+            } else { err = FQZO_E_ENTROPY; break; }
             if (last) break;
         }
+        free(hs);
+        if (err) return err;
         if (ck) { if (ip + 4 > n) return FQZO_E_ENTROPY; ip += 4; /* XXH64 low 32 bits: not verified */ }
         if (fcs >= 0 && (size_t)fcs != out - frame_start) return FQZO_E_ENTROPY;
     }

@@ -149,6 +149,7 @@ long fqzo_join_block_size(const uint8_t *const data[FQZO_NSTREAMS], const size_t
  * the HIP encoder must produce identical bytes (spec in DESIGN.md §Entropy).
  */
 #define FQZO_CHUNK 16384u
+#define FQZO_GROUP 4u   /* chunks that share one Huffman table */
 size_t fqzo_entropy_bound(size_t n);
 /* Returns frame size; n==0 -> 0 bytes (klauspost EncodeAll without zero frames). */
 size_t fqzo_entropy_encode(const uint8_t *src, size_t n, uint8_t *dst);
@@ -171,6 +172,7 @@ void fqzo_huf_codes(const uint8_t nbits[256], int max_bits, uint16_t code[256]);
 size_t fqzo_huf_write_tree(const uint8_t nbits[256], int max_bits, uint8_t *dst);
 /* One zstd block for chunk [src, src+m): returns bytes written. */
 size_t fqzo_encode_chunk(const uint8_t *src, size_t m, int last, uint8_t *dst);
+size_t fqzo_encode_group(const uint8_t *src, size_t M, int last, uint8_t *dst); /* up to FQZO_GROUP chunks sharing one Huffman table */
 
 /* ---- whole-file pipeline: compress.Compress / compress.Decompress ------ */
 typedef struct {
