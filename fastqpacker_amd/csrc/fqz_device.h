@@ -120,6 +120,38 @@ __device__ __forceinline__ uint32_t piece_owner(uint32_t incl, uint32_t p)
 
 // the first nb (<= 16) bytes of w[] to dst (any alignment): one 128-bit store, or for a tail at most four stores of
 // 8 / 4 / 2 / 1 bytes — never a byte loop (a divergent 15-iteration loop per tail piece cost more than the whole rest)
+// piece p -> (record i of the wave's 64, piece k inside it).  incl = wave inclusive scan of the per-record piece
+// counts cnt.  When every record that has pieces has the same count (fixed-length reads: the common case) the map is a
+// division by a wave-uniform constant and needs no cross-lane traffic; otherwise a binary search over incl
+// (ds_bpermute).  Every lane of the wave must call these.
+struct PieceMap { uint32_t uni; float inv; };
+__device__ __forceinline__ PieceMap piece_map_make(uint32_t cnt, uint32_t incl)
+{
+    PieceMap m;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+    // uniform <=> lanes 0..n-1 all have c0 pieces and the rest none, i.e. incl is min(lane + 1, n) * c0
+    const bool odd = c0 == 0 || (cnt != c0 && cnt != 0) || (cnt == 0 && incl != total) || total > (1u << 22);
+    m.uni = __ballot(odd) ? 0u : c0;
+    m.inv = m.uni ? 1.0f / (float)m.uni : 0.0f;
+    return m;
+}
+__device__ __forceinline__ void piece_locate(const PieceMap &m, uint32_t incl, uint32_t cnt, uint32_t p, uint32_t *i, uint32_t *k)
+{
+    if (m.uni) {
+        uint32_t q = (uint32_t)(((float)p + 0.5f) * m.inv); // p < 2^22; off by one at most, fixed below
+        if (q * m.uni > p) q--;
+        if ((q + 1) * m.uni <= p) q++;
+        q = q > 63 ? 63 : q;
+        *i = q;
+        *k = p - q * m.uni;
+    } else {
+        const uint32_t o = piece_owner(incl, p);
+        *i = o;
+        *k = p - (uint32_t)__shfl((int)(incl - cnt), (int)o, WAVE);
+    }
+}
+
 __device__ __forceinline__ void store_piece(uint8_t *dst, const uint32_t w[4], uint32_t nb)
 {
     if (nb >= 16) { store_u128_unaligned(dst, make_uint4(w[0], w[1], w[2], w[3])); return; }

@@ -560,14 +560,15 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
         }
         const uint32_t pq = (L + 15) >> 4, ph = (H + 15) >> 4, pp = (P + 15) >> 4;
         const uint32_t iq = wave_incl_scan(pq), ih = wave_incl_scan(ph), ip = wave_incl_scan(pp);
+        const PieceMap pm_iq = piece_map_make(pq, iq), pm_ih = piece_map_make(ph, ih), pm_ip = piece_map_make(pp, ip);
         const uint32_t Tq = (uint32_t)RL(iq, 63), Th = (uint32_t)RL(ih, 63), Tp = (uint32_t)RL(ip, 63);
 
         // ---- bases: 16 bases -> 4 packed bytes (sequence.go:139-184); N counts go to E[nPos] (compress.go:477-488)
         for (uint32_t base = 0; base < Tq; base += WAVE) {
             const uint32_t p = base + lane;
             const bool on = p < Tq;
-            const uint32_t i = piece_owner(iq, on ? p : 0);
-            const uint32_t k = p - (uint32_t)__shfl((int)(iq - pq), (int)i, WAVE);
+            uint32_t i, k;
+            piece_locate(pm_iq, iq, pq, on ? p : 0, &i, &k);
             const uint32_t Li = (uint32_t)__shfl((int)L, (int)i, WAVE), src = (uint32_t)__shfl((int)s_seq, (int)i, WAVE);
             const uint32_t dst = (uint32_t)__shfl((int)d_seq, (int)i, WAVE);
             if (on) {
@@ -609,8 +610,8 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
         for (uint32_t base = 0; base < Tq; base += WAVE) {
             const uint32_t p = base + lane;
             const bool on = p < Tq;
-            const uint32_t i = piece_owner(iq, on ? p : 0);
-            const uint32_t k = p - (uint32_t)__shfl((int)(iq - pq), (int)i, WAVE);
+            uint32_t i, k;
+            piece_locate(pm_iq, iq, pq, on ? p : 0, &i, &k);
             const uint32_t Li = (uint32_t)__shfl((int)L, (int)i, WAVE), src = (uint32_t)__shfl((int)s_qual, (int)i, WAVE);
             const uint32_t dst = (uint32_t)__shfl((int)d_qual, (int)i, WAVE);
             if (on) {
@@ -626,8 +627,8 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
         for (uint32_t base = 0; base < Th; base += WAVE) {
             const uint32_t p = base + lane;
             const bool on = p < Th;
-            const uint32_t i = piece_owner(ih, on ? p : 0);
-            const uint32_t k = p - (uint32_t)__shfl((int)(ih - ph), (int)i, WAVE);
+            uint32_t i, k;
+            piece_locate(pm_ih, ih, ph, on ? p : 0, &i, &k);
             const uint32_t Hi = (uint32_t)__shfl((int)H, (int)i, WAVE), src = (uint32_t)__shfl((int)s_hdr, (int)i, WAVE);
             const uint32_t dst = (uint32_t)__shfl((int)d_hdr, (int)i, WAVE);
             if (on) {
@@ -639,8 +640,8 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
         for (uint32_t base = 0; base < Tp; base += WAVE) {
             const uint32_t p = base + lane;
             const bool on = p < Tp;
-            const uint32_t i = piece_owner(ip, on ? p : 0);
-            const uint32_t k = p - (uint32_t)__shfl((int)(ip - pp), (int)i, WAVE);
+            uint32_t i, k;
+            piece_locate(pm_ip, ip, pp, on ? p : 0, &i, &k);
             const uint32_t Pi = (uint32_t)__shfl((int)P, (int)i, WAVE), src = (uint32_t)__shfl((int)s_plus, (int)i, WAVE);
             const uint32_t dst = (uint32_t)__shfl((int)d_plus, (int)i, WAVE);
             if (on) {
