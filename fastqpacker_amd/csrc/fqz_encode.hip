@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 }
 
 // N positions: u16 count + ascending u16 positions per record (compress.go:477-488, 507-512)
-__global__ __launch_bounds__(256) void k_npos_write(const uint8_t *text, const uint32_t *ls, EncInfo *info, const uint32_t *E, uint32_t estride,
+__global__ __launch_bounds__(256) void k_npos_write(const uint8_t *text, uint32_t n_text, const uint32_t *ls, EncInfo *info, const uint32_t *E, uint32_t estride,
                                                     const BlockPlan *plans, uint32_t rpb, uint8_t *npos_arena)
 {
     const uint32_t n_rec = info->n_rec;
@@ -737,26 +737,52 @@ __global__ __launch_bounds__(256) void k_npos_write(const uint8_t *text, const u
             dn[0] = (uint8_t)NN; dn[1] = (uint8_t)(NN >> 8);
             if (NN) { s_seq = ls[4 * r + 1]; L = Equal[r + 1] - Equal[r]; }
         }
-        unsigned long long todo = __ballot(NN != 0);
-        while (todo) {
-            const int i = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const uint32_t Li = (uint32_t)RL(L, i);
-            const uint8_t *sq = text + (uint32_t)RL(s_seq, i);
-            uint8_t *dst = npos_arena + (uint32_t)RL(d_npos, i);
-            uint32_t limit = Li < FQZ_MAX_SEQUENCE_LENGTH ? Li : FQZ_MAX_SEQUENCE_LENGTH, run = 0;
-            for (uint32_t base = 0; base < limit; base += WAVE) {
-                uint32_t k = base + lane;
-                bool inv = false;
-                if (k < limit) inv = (acgt_mask((uint32_t)sq[k] * 0x01010101u) & 0x80u) == 0;
-                unsigned long long mk = __ballot(inv);
-                if (inv) {
-                    uint32_t w = run + __popcll(mk & ((1ull << lane) - 1));
-                    dst[2 + 2 * w] = (uint8_t)k;
-                    dst[3 + 2 * w] = (uint8_t)(k >> 8);
+        // Piece-centric like k_split: the reads that have N are cut into 16-base pieces, a lane finds the non-ACGT bases of
+        // one piece and writes their positions after those of the earlier pieces of the same read (wave scan of the
+        // per-piece counts minus its value at the read's first piece; a read that continues from the previous round takes
+        // the carried count).  With N in most reads (5 % N) the old one-read-at-a-time loop cost as much as k_split.
+        const uint32_t limit = L < FQZ_MAX_SEQUENCE_LENGTH ? L : FQZ_MAX_SEQUENCE_LENGTH; // positions >= 65536 are not recorded
+        const uint32_t pn = NN ? (limit + 15) >> 4 : 0;
+        const uint32_t in_ = wave_incl_scan(pn);
+        const uint32_t Tn = (uint32_t)RL(in_, 63);
+        const PieceMap pm = piece_map_make(pn, in_);
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < Tn; base += WAVE) {
+            const uint32_t p = base + lane;
+            const bool on = p < Tn;
+            uint32_t i, k;
+            piece_locate(pm, in_, pn, on ? p : 0, &i, &k);
+            const uint32_t lim_i = (uint32_t)__shfl((int)limit, (int)i, WAVE), src = (uint32_t)__shfl((int)s_seq, (int)i, WAVE);
+            const uint32_t dst = (uint32_t)__shfl((int)d_npos, (int)i, WAVE);
+            uint32_t bad16 = 0; // bit b: base 16 k + b is not one of ACGTacgt
+            if (on) {
+                uint32_t x[4];
+                load_piece(text, (size_t)src + 16 * k, n_text, x);
+                const uint32_t have = lim_i - 16 * k < 16 ? lim_i - 16 * k : 16;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t inv = ~acgt_mask(x[q]) & 0x80808080u;
+                    bad16 |= ((((inv >> 7) & 0x01010101u) * 0x01020408u) >> 24) << (4 * q);
                 }
-                run += __popcll(mk);
+                bad16 &= have >= 16 ? 0xFFFFu : ((1u << have) - 1);
             }
+            const uint32_t cntp = __popc(bad16);
+            const uint32_t incl = wave_incl_scan(cntp), excl = incl - cntp;
+            const uint32_t head_excl = (uint32_t)__shfl((int)excl, (int)(lane >= k ? lane - k : 0), WAVE);
+            uint32_t rank = lane >= k ? excl - head_excl : carry + excl;
+            if (on) {
+                uint8_t *o = npos_arena + dst + 2;
+                uint32_t m2 = bad16;
+                while (m2) {
+                    const uint32_t bpos = 16 * k + (uint32_t)(__ffs(m2) - 1);
+                    m2 &= m2 - 1;
+                    o[2 * rank] = (uint8_t)bpos;
+                    o[2 * rank + 1] = (uint8_t)(bpos >> 8);
+                    rank++;
+                }
+            }
+            const uint32_t before_l = lane >= k ? excl - head_excl : carry + excl;
+            carry = (uint32_t)RL(before_l + cntp, 63); // only read by lanes whose read started before the next round
         }
     }
 }
@@ -991,7 +1017,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
     if ((rc = launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap))) return rc;
     PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
-    PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, ls, info, E, estride, plans, rpb, npos));
+    PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, npos));
     const uint32_t group_cap = e.chunk_cap / FQZ_GROUP + FQZ_NS * e.block_cap + 8;
     if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
     PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap));
