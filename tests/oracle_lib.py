@@ -307,3 +307,18 @@ def zstd_compress(data: bytes, level=1) -> bytes:
     if z.ZSTD_isError(r):
         raise ValueError("libzstd: " + z.ZSTD_getErrorName(r).decode())
     return out.raw[:r]
+
+
+def group_cases():
+    """streams whose 16 KiB chunks differ inside a 64 KiB group (one Huffman table per group)"""
+    rng = np.random.default_rng(23)
+    skew = lambda n: bytes(np.minimum(rng.geometric(0.4, n) - 1, 40).astype(np.uint8))
+    flat = lambda n: bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    C = 16384
+    yield "rle-chunk-first", b"\x07" * C + skew(3 * C)                       # the tree travels with the second block
+    yield "rle-chunk-in-the-middle", skew(C) + b"\x00" * C + skew(2 * C)
+    yield "raw-chunk-inside-a-huffman-group", skew(C) + flat(C) + skew(2 * C)  # flat chunk: group table cannot shrink it
+    yield "raw-chunk-first", flat(C) + skew(3 * C)                              # first Compressed block is the second chunk
+    yield "two-groups-and-a-tail", skew(4 * C) + skew(4 * C) + skew(C + 77)
+    yield "tail-group-of-tiny-chunk", skew(4 * C) + skew(5)
+    yield "alternating-alphabets", b"".join((skew(C) if k % 2 else bytes(rng.choice([65, 67, 71, 84], C).astype(np.uint8))) for k in range(8))

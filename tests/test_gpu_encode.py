@@ -82,10 +82,12 @@ def test_entropy_stage_matches_oracle(fq):
     ]
     for n in [1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 16383, 16384, 16385, 16384 * 3 + 5]:
         cases.append(bytes(rng.choice([0, 1, 2, 255, 254, 7], n, p=[.6, .15, .1, .1, .03, .02]).astype(np.uint8)))
+    cases += [d for _, d in O.group_cases()]
     for i, data in enumerate(cases):
         got = fq.compress.entropy_encode(data)
         want = O.entropy_encode(data)
         assert got == want, _dump_diff("case %d (n=%d)" % (i, len(data)), got, want)
+        assert fq.compress.entropy_decode(got, len(data)) == data
 
 
 def test_multi_block_batch_matches_oracle(fq):

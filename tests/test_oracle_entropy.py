@@ -26,7 +26,8 @@ def _cases():
 
 @needs_zstd
 def test_frames_decode_with_libzstd():
-    for name, data in _cases():
+    import itertools
+    for name, data in itertools.chain(_cases(), O.group_cases()):
         f = O.entropy_encode(data)
         if not data:
             assert f == b""
@@ -37,7 +38,8 @@ def test_frames_decode_with_libzstd():
 
 
 def test_own_decoder_roundtrip_and_rejects_garbage():
-    for name, data in _cases():
+    import itertools
+    for name, data in itertools.chain(_cases(), O.group_cases()):
         assert O.entropy_decode(O.entropy_encode(data), len(data)) == data, name
     f = bytearray(O.entropy_encode(bytes(np.random.default_rng(1).integers(0, 4, 20000, dtype=np.uint8))))
     with pytest.raises(O.OracleError):
@@ -93,3 +95,19 @@ def test_oracle_decodes_foreign_zstd_frames_via_libzstd():
     text = make_fastq(300, seed=9)
     z = O.compress(text, entropy=1)
     assert O.decompress(z) == text
+
+
+def test_group_shapes_use_treeless_blocks():
+    """the blocks after the first Compressed block of a group are treeless (Literals_Block_Type 3)"""
+    data = dict(O.group_cases())["two-groups-and-a-tail"]
+    f = O.entropy_encode(data)
+    pos, types = 10, []
+    while True:
+        bh = int.from_bytes(f[pos:pos + 3], "little")
+        last, btype, bs = bh & 1, (bh >> 1) & 3, bh >> 3
+        types.append((btype, f[pos + 3] & 3 if btype == 2 else None))
+        pos += 3 + (1 if btype == 1 else bs)
+        if last:
+            break
+    assert pos == len(f)
+    assert types == [(2, 2), (2, 3), (2, 3), (2, 3)] * 2 + [(2, 2), (2, 3)]
