@@ -95,7 +95,7 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     EncState &e = c->enc;
-    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.stamps, &e.lf, &e.rs_state, &e.scan_state, &e.gmap};
+    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.stamps, &e.lf, &e.zstate, &e.scan_state, &e.gmap};
     for (DevBuf *b : eb) b->release();
     e.h_info.release(); e.h_plans.release();
     DecState &d = c->dec;

@@ -72,7 +72,7 @@ struct EncState {
     DevBuf ls;        // u32[line_cap+1] line starts
     DevBuf lf;        // u8[line_cap+1] line flags: '\r' before the newline | first-byte class << 1
     DevBuf E;         // u32[5][rec_cap+1]: seq, qual, hdr, plus, npos sizes -> exclusive offsets
-    DevBuf rs_state;  // look-back states of k_record_scan + its ticket
+    DevBuf zstate;    // look-back states and tickets of the batch's scans (zeroed by k_init)
     DevBuf scan_state; // look-back states of k_scan + its ticket
     DevBuf gmap;      // chunk-group descriptors (k_group_map)
     DevBuf plans;     // BlockPlan[block_cap]

@@ -94,15 +94,20 @@ __global__ __launch_bounds__(256) void k_scan(uint32_t *__restrict__ data, const
 }
 
 // data: n_cap + 1 u32, scanned in place; data[n] receives the total
-static int launch_scan(fqz_ctx *ctx, const char *label, hipStream_t st, uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t n_cap)
+// state: tiles + 1 zeroed 64-bit words (the batch encoder zeroes all its look-back states in k_init); nullptr: own buffer + memset
+static int launch_scan(fqz_ctx *ctx, const char *label, hipStream_t st, uint32_t *data, const uint32_t *n_ptr, uint32_t n_add, uint32_t n_cap,
+                       unsigned long long *state = nullptr)
 {
     const uint32_t tiles = n_cap / SCAN_TILE + 1;
-    DevBuf &sb = ctx->enc.scan_state;
-    int rc = sb.ensure(8ull * ((size_t)tiles + 1));
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(sb.p, 0, 8ull * ((size_t)tiles + 1), st));
+    if (!state) {
+        DevBuf &sb = ctx->enc.scan_state;
+        int rc = sb.ensure(8ull * ((size_t)tiles + 1));
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(sb.p, 0, 8ull * ((size_t)tiles + 1), st));
+        state = sb.as<unsigned long long>();
+    }
     ctx->prof.begin(label, st);
-    hipLaunchKernelGGL(k_scan, dim3(tiles), dim3(256), 0, st, data, n_ptr, n_add, sb.as<unsigned long long>(), tiles);
+    hipLaunchKernelGGL(k_scan, dim3(tiles), dim3(256), 0, st, data, n_ptr, n_add, state, tiles);
     ctx->prof.end(st);
     return FQZ_OK;
 }
@@ -110,8 +115,9 @@ static int launch_scan(fqz_ctx *ctx, const char *label, hipStream_t st, uint32_t
 // ===========================================================================
 // K0 line index (parser.go:209-243 readLine)
 // ===========================================================================
-__global__ __launch_bounds__(256) void k_init(EncInfo *info, int qual_encoding)
+__global__ __launch_bounds__(256) void k_init(EncInfo *info, int qual_encoding, unsigned long long *zstate, uint32_t zwords)
 {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < zwords; i += gridDim.x * 256) zstate[i] = 0; // look-back states and tickets
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         EncInfo z;
         memset(&z, 0, sizeof z);
@@ -971,7 +977,6 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.ls.ensure(4ull * (e.line_cap + 8)))) return rc;
     if ((rc = e.lf.ensure(e.line_cap + 8))) return rc;
     if ((rc = e.E.ensure(4ull * 5 * estride))) return rc;
-    if ((rc = e.rs_state.ensure(8ull * (4ull * (e.rec_cap / RS_TILE + 1) + 1)))) return rc;
     if ((rc = e.plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
     if ((rc = e.arena.ensure(e.arena_cap + 64))) return rc;
     if ((rc = e.npos.ensure(e.npos_cap + 64))) return rc;
@@ -990,10 +995,15 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     BlockPlan *plans = e.plans.as<BlockPlan>();
     uint8_t *arena = e.arena.as<uint8_t>(), *npos = e.npos.as<uint8_t>(), *slots = e.slots.as<uint8_t>();
 
-    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, qual_encoding);
+    // one zeroed buffer for every look-back state of the batch: [tile scan | nPos scan | chunk scan | record scan]
+    const uint32_t zt_tiles = e.n_tiles / SCAN_TILE + 2, zt_npos = e.rec_cap / SCAN_TILE + 2, zt_chunks = e.chunk_cap / SCAN_TILE + 2;
+    const uint32_t rs_tiles = e.rec_cap / RS_TILE + 1, zwords = zt_tiles + zt_npos + zt_chunks + 4 * rs_tiles + 1;
+    if ((rc = e.zstate.ensure(8ull * zwords))) return rc;
+    unsigned long long *z_tiles = e.zstate.as<unsigned long long>(), *z_npos = z_tiles + zt_tiles, *z_chunks = z_npos + zt_npos, *rs_state = z_chunks + zt_chunks;
+    hipLaunchKernelGGL(k_init, dim3((zwords + 255) / 256 < 64 ? (zwords + 255) / 256 : 64), dim3(256), 0, st, info, qual_encoding, z_tiles, zwords);
     if (e.n_tiles) {
         PROF(ctx, st, "k_count_nl", hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile));
-        if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles))) return rc;
+        if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, z_tiles))) return rc;
         PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts, dim3((e.n_tiles + LI_SUB - 1) / LI_SUB), dim3(256), 0, st, d_text, n, e.n_tiles, tile, ls, lf, e.line_cap));
     } else {
         HIP_TRY(hipMemsetAsync(tile, 0, 8, st));
@@ -1003,9 +1013,6 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, st, "k_setup_records", hipLaunchKernelGGL(k_setup_records, dim3(1), dim3(64), 0, st, info, tile, e.n_tiles, ls, e.line_cap, e.rec_cap, e.block_cap, rpb,
                        final_batch, n));
     {
-        const uint32_t rs_tiles = e.rec_cap / RS_TILE + 1;
-        unsigned long long *rs_state = e.rs_state.as<unsigned long long>();
-        HIP_TRY(hipMemsetAsync(rs_state, 0, 8ull * (4ull * rs_tiles + 1), st));
         PROF(ctx, st, "k_record_scan", hipLaunchKernelGGL(k_record_scan, dim3(rs_tiles), dim3(256), 0, st, ls, lf, info, E, estride, final_batch, rs_state,
                                                         (uint32_t *)(rs_state + 4ull * rs_tiles)));
     }
@@ -1015,14 +1022,14 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     }
     PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(256), 0, st, info, E, estride, plans, rpb, e.arena_cap, (uint32_t)main_cap));
     PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
-    if ((rc = launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap))) return rc;
+    if ((rc = launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, z_npos))) return rc;
     PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
     PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, npos));
     const uint32_t group_cap = e.chunk_cap / FQZ_GROUP + FQZ_NS * e.block_cap + 8;
     if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
     PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
-    if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap))) return rc;
+    if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out));
     HIP_TRY(hipGetLastError());
@@ -1132,7 +1139,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     EncInfo *info = e.info.as<EncInfo>();
     BlockPlan *plans = e.plans.as<BlockPlan>();
     uint32_t *csize = e.csize.as<uint32_t>();
-    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, info, 0);
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(256), 0, st, info, 0, (unsigned long long *)nullptr, 0u);
     hipLaunchKernelGGL(k_single_plan, dim3(1), dim3(64), 0, st, info, plans, (uint32_t)n);
     const uint32_t group_cap = chunks / FQZ_GROUP + 8;
     if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
