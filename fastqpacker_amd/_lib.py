@@ -167,7 +167,8 @@ class Ctx:
 
 
 def _ctx_profile(self, on=True):
-    check(lib().fqz_profile_enable(self._h, 1 if on else 0))
+    """False/0 off, True/1 every kernel, 2 only the dominant encode kernel (k_entropy)"""
+    check(lib().fqz_profile_enable(self._h, int(on)))
     check(lib().fqz_profile_reset(self._h))
 
 

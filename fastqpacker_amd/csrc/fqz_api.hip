@@ -702,6 +702,7 @@ extern "C" int fqz_profile_enable(fqz_ctx *ctx, int on)
 {
     if (!ctx) return FQZ_E_ARG;
     ctx->prof.on = on != 0;
+    ctx->prof.dominant_only = on == 2;
     return FQZ_OK;
 }
 extern "C" int fqz_profile_reset(fqz_ctx *ctx)

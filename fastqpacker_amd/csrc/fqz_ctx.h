@@ -1,5 +1,6 @@
 // fqz_ctx.h — the context object behind the opaque fqz_ctx of include/fqz.h.
 #pragma once
+#include <string.h>
 #include "fqz_internal.h"
 
 #include <string>
@@ -108,6 +109,8 @@ struct ProfEntry { const char *name; hipEvent_t a, b; };
 struct ProfTotal { std::string name; double ms; uint32_t calls; };
 struct Prof {
     bool on = false;
+    bool dominant_only = false; // bracket only k_entropy (two events per batch instead of ~40: nothing to perturb the timed region)
+    bool armed = false;
     std::vector<ProfEntry> pending;
     std::vector<hipEvent_t> pool;
     std::vector<ProfTotal> totals;
@@ -120,15 +123,17 @@ struct Prof {
     }
     void begin(const char *name, hipStream_t st)
     {
-        if (!on) return;
+        armed = on && (!dominant_only || !strcmp(name, "k_entropy"));
+        if (!armed) return;
         ProfEntry e{name, get(), get()};
         (void)hipEventRecord(e.a, st);
         pending.push_back(e);
     }
     void end(hipStream_t st)
     {
-        if (!on || pending.empty()) return;
+        if (!armed || pending.empty()) return;
         (void)hipEventRecord(pending.back().b, st);
+        armed = false;
     }
     void collect() // call after the stream has been synchronised
     {
