@@ -3,7 +3,7 @@
 // Replaces, for a batch of blocks at once, the reference's
 //   fqparser.nextInto/readLine            internal/fqparser/parser.go:136-243   (k_count_nl, k_line_starts, k_record_scan)
 //   encoder.DetectEncoding                internal/encoder/quality.go:22-49     (k_detect)
-//   compressBlockWithBuffers record loop  internal/compress/compress.go:474-520 (k_split_seq, k_split_rest)
+//   compressBlockWithBuffers record loop  internal/compress/compress.go:474-520 (k_split, k_npos_write)
 //     encoder.AppendPackedBases           internal/encoder/sequence.go:139-184
 //     encoder.NormalizeQuality+DeltaEncode internal/encoder/quality.go:53-103
 //   6 x zstd.Encoder.EncodeAll            compress.go:523-528                   (k_entropy: Huffman-literal zstd blocks)

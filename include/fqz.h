@@ -57,7 +57,7 @@ typedef enum {
     FQZ_E_HIP = -30,           /* HIP runtime error (fqz_last_hip_error) */
     FQZ_E_NO_DEVICE = -31,     /* no HIP device: the product path never falls back to CPU */
     FQZ_E_ARG = -32,
-    FQZ_E_TOO_LARGE = -33,     /* batch >= 4 GiB of FASTQ text (device offsets are u32) */
+    FQZ_E_TOO_LARGE = -33,     /* batch >= 2 GiB of FASTQ text (device offsets are 32 bits); slice the input */
     FQZ_E_IO = -34
 } fqz_status;
 
@@ -147,7 +147,7 @@ typedef struct {
  * d_out receives the blocks back to back (no file header); block_off[b] /
  * block_len[b] (host arrays, may be NULL, capacity max_blocks) locate them.
  * `stream` is a hipStream_t (NULL = the context's own stream).  Synchronous
- * on return: the result struct is valid. n_bytes must be < 4 GiB. */
+ * on return: the result struct is valid. n_bytes must be < 2 GiB (fqz_compress slices larger inputs into batches). */
 int fqz_encode_batch_dev(fqz_ctx *ctx, const uint8_t *d_fastq, size_t n_bytes, uint32_t records_per_block,
                          int qual_encoding, uint32_t flags, uint8_t *d_out, size_t out_cap,
                          fqz_batch_result *res, uint64_t *block_off, uint64_t *block_len, size_t max_blocks,
