@@ -693,13 +693,15 @@ __device__ __forceinline__ void locate_chunk(const EncInfo *info, const BlockPla
 
 // groups of up to FQZ_GROUP consecutive chunks of one stream share a Huffman table: one thread per chunk finds the
 // group leaders and appends a descriptor {first chunk id, arena offset, bytes | last << 24 | stream << 28, 0}
-__global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPlan *plans, uint4 *gmap, uint32_t group_cap)
+// cinfo[chunk] = block | stream << 24, for k_compact (which would otherwise repeat the search, one dependent load after another)
+__global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPlan *plans, uint4 *gmap, uint32_t group_cap, uint32_t *cinfo)
 {
     const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
     if (chunk >= info->n_chunks) return;
     uint32_t b, c;
     int s;
     locate_chunk(info, plans, chunk, &b, &s, &c);
+    cinfo[chunk] = b | ((uint32_t)s << 24);
     if (c % FQZ_GROUP) return;
     const BlockPlan *p = &plans[b];
     const uint32_t off = c * FQZ_CHUNK;
@@ -872,37 +874,27 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
     }
 }
 
+// One workgroup per chunk: slot (16-byte aligned) -> its place in the frame (any alignment).  The destination comes from
+// three dependent loads (cinfo -> plan -> scanned sizes), uniform across the workgroup, so they go through the scalar unit;
+// the body is copied in 16-byte rows aligned to the destination.
 __global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const BlockPlan *plans, const uint8_t *slots, const uint32_t *cpre,
-                                                 uint8_t *out)
+                                                 const uint32_t *cinfo, uint8_t *out)
 {
-    __shared__ uint32_t sh[2];
     const uint32_t chunk = blockIdx.x;
     if (info->status || chunk >= info->n_chunks) return;
     const uint32_t t = threadIdx.x;
-    if (t == 0) {
-        uint32_t b, c;
-        int s;
-        locate_chunk(info, plans, chunk, &b, &s, &c);
-        const BlockPlan *p = &plans[b];
-        sh[0] = p->frame_off[s] + 10 + (cpre[chunk] - cpre[p->chunk_base[s]]);
-        sh[1] = cpre[chunk + 1] - cpre[chunk];
-    }
-    __syncthreads();
-    uint8_t *dst = out + sh[0];
-    const uint32_t n = sh[1];
-    const uint8_t *src = slots + (size_t)chunk * FQZ_SLOT; // 16-byte aligned
-    uint32_t head = (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3);
+    const uint32_t ci = cinfo[chunk], c0 = cpre[chunk], c1 = cpre[chunk + 1];
+    const BlockPlan *p = &plans[ci & 0xFFFFFFu];
+    const uint32_t s = ci >> 24;
+    uint8_t *dst = out + p->frame_off[s] + 10 + (c0 - cpre[p->chunk_base[s]]);
+    const uint32_t n = c1 - c0;
+    const uint8_t *src = slots + (size_t)chunk * FQZ_SLOT;
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
     if (head > n) head = n;
     if (t < head) dst[t] = src[t];
-    uint32_t body = (n - head) >> 2;
-    const uint32_t *s32 = (const uint32_t *)src;
-    uint32_t *d32 = (uint32_t *)(dst + head);
-    for (uint32_t j = t; j < body; j += 256) {
-        uint32_t sb = head + 4 * j;          // source byte offset of this dword
-        uint32_t lo = s32[sb >> 2], hi = s32[(sb >> 2) + 1]; // slot padding keeps hi in bounds
-        d32[j] = __builtin_amdgcn_alignbyte(hi, lo, sb & 3);
-    }
-    uint32_t tail0 = head + 4 * body;
+    const uint32_t rows = (n - head) >> 4;
+    for (uint32_t j = t; j < rows; j += 256) *(uint4 *)(dst + head + 16 * j) = load_u128_unaligned(src + head + 16 * j);
+    const uint32_t tail0 = head + 16 * rows;
     if (t < n - tail0) dst[tail0 + t] = src[tail0 + t];
 }
 
@@ -981,7 +973,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.arena.ensure(e.arena_cap + 64))) return rc;
     if ((rc = e.npos.ensure(e.npos_cap + 64))) return rc;
     if ((rc = e.slots.ensure((size_t)e.chunk_cap * FQZ_SLOT))) return rc;
-    if ((rc = e.csize.ensure(4ull * (e.chunk_cap + 2)))) return rc;
+    if ((rc = e.csize.ensure(4ull * (2ull * e.chunk_cap + 4)))) return rc; // compressed sizes (scanned in place) | cinfo
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
     if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
 
@@ -1027,11 +1019,11 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, npos));
     const uint32_t group_cap = e.chunk_cap / FQZ_GROUP + FQZ_NS * e.block_cap + 8;
     if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
-    PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap));
+    PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap, csize + e.chunk_cap + 2));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
-    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, d_out));
+    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, d_out));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
     e.in_flight = true;
@@ -1134,7 +1126,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     if ((rc = e.info.ensure(sizeof(EncInfo)))) return rc;
     if ((rc = e.plans.ensure(sizeof(BlockPlan) * 2))) return rc;
     if ((rc = e.slots.ensure((size_t)(chunks + 1) * FQZ_SLOT))) return rc;
-    if ((rc = e.csize.ensure(4ull * (chunks + 2)))) return rc;
+    if ((rc = e.csize.ensure(4ull * (2ull * chunks + 4)))) return rc;
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
     EncInfo *info = e.info.as<EncInfo>();
     BlockPlan *plans = e.plans.as<BlockPlan>();
@@ -1143,11 +1135,11 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     hipLaunchKernelGGL(k_single_plan, dim3(1), dim3(64), 0, st, info, plans, (uint32_t)n);
     const uint32_t group_cap = chunks / FQZ_GROUP + 8;
     if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
-    hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap);
+    hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap, csize + chunks + 2);
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;
     hipLaunchKernelGGL(k_single_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_dst, cap);
-    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, d_dst));
+    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, csize + chunks + 2, d_dst));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
