@@ -13,15 +13,15 @@ src = os.path.join(root, "gpurun_out", "prof")
 dst = os.path.join(root, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 lines = []
-stats = glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True)
+stats = sorted(glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime, reverse=True)  # gpurun_out accumulates: newest run
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "rocprofv3_kernel_stats_bench_steps5.csv"))
-    lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu --decode-steps 1 --inflight 0")
+    lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu --decode-steps 1 --inflight 0  (encode kernels: 1 warm-up + 5 timed + 3 per-kernel breakdown steps)")
     for r in csv.DictReader(open(stats[0])):
         lines.append("%-34s calls %5s total_ns %12s avg_ns %12s pct %6s" % (r.get("Name", "")[:34], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 pmc = {}
 for tag, key in (("fetch", "FETCH_SIZE_KiB"), ("write", "WRITE_SIZE_KiB")):
-    for f in glob.glob(src + "/pmc_%s/**/*counter_collection.csv" % tag, recursive=True):
+    for f in sorted(glob.glob(src + "/pmc_%s/**/*counter_collection.csv" % tag, recursive=True), key=os.path.getmtime, reverse=True)[:1]:
         agg = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
             k = r.get("Kernel_Name", "").split("(")[0]
