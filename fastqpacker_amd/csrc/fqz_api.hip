@@ -209,12 +209,13 @@ extern "C" int fqz_encode_batch_dev(fqz_ctx *ctx, const uint8_t *d_fastq, size_t
                                     uint32_t flags, uint8_t *d_out, size_t out_cap, fqz_batch_result *res, uint64_t *block_off,
                                     uint64_t *block_len, size_t max_blocks, void *stream)
 {
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 3; attempt++) {
         int rc = fqz_encode_batch_launch(ctx, d_fastq, n_bytes, records_per_block, qual_encoding, flags, d_out, out_cap, stream);
         if (rc) return rc;
         rc = fqz_encode_batch_finish(ctx, res, block_off, block_len, max_blocks);
-        // more lines than the optimistic line-table capacity: finish() recorded the exact need; run again
-        if (rc == FQZ_E_TOO_LARGE && attempt == 0) continue;
+        // very short lines: a tile-local line slot overflowed (finish() switched the context to the two-pass index) and / or
+        // there are more lines than the optimistic line-table capacity (finish() recorded the exact need): run again
+        if (rc == FQZ_E_TOO_LARGE && attempt < 2) continue;
         return rc;
     }
     return FQZ_E_TOO_LARGE;

@@ -160,8 +160,17 @@ __global__ __launch_bounds__(256) void k_count_nl(const uint8_t *text, uint32_t 
 // newline counts are scanned together, packed 2 x 16 bits, and every tile adds its own base from the tile scan.
 // The bytes either side of a newline come from registers (neighbouring threads' edge bytes through LDS).
 #define LI_SUB 4u
+//
+// LOCAL (the default path): the text is read ONCE.  Nothing is known about the tiles before this one, so a tile's
+// entries go to its own slot of LL_CAP entries (lsl / lfl, tile-local index), its newline count to tile_cnt; after
+// the scan of the counts k_line_gather moves the entries to their global places (57 MB instead of a second pass over
+// the text to count newlines first).  A tile with more than LL_CAP lines (lines under 8 bytes on average) raises
+// info->index_overflow and the batch is redone with the two-pass path (k_count_nl, scan, this kernel with LOCAL = false).
+#define LL_CAP 512u
+template <bool LOCAL>
 __global__ __launch_bounds__(256) void k_line_starts(const uint8_t *__restrict__ text, uint32_t n, uint32_t n_tiles, const uint32_t *__restrict__ tile_off,
-                                                     uint32_t *__restrict__ ls, uint8_t *__restrict__ lf, uint32_t line_cap)
+                                                     uint32_t *__restrict__ ls, uint8_t *__restrict__ lf, uint32_t line_cap,
+                                                     uint32_t *__restrict__ lsl, uint8_t *__restrict__ lfl, uint32_t *__restrict__ tile_cnt, EncInfo *info)
 {
     __shared__ uint32_t sh_lo[4], sh_hi[4], s_ext[2];
     __shared__ uint16_t edge[LI_SUB][258]; // [q][t + 1] = first byte | last byte << 8 of thread t's 16 bytes of tile q
@@ -198,10 +207,19 @@ __global__ __launch_bounds__(256) void k_line_starts(const uint8_t *__restrict__
         ls[0] = 0;
         lf[0] = (uint8_t)(n ? (((w[0][0] & 0xFF) == '@' ? 1 : (w[0][0] & 0xFF) == '+' ? 2 : 0) << 1) : 0);
     }
+    if (LOCAL && t == 0) {
+        const uint32_t tot_lo = sh_lo[0] + sh_lo[1] + sh_lo[2] + sh_lo[3], tot_hi = sh_hi[0] + sh_hi[1] + sh_hi[2] + sh_hi[3];
+        const uint32_t tot[LI_SUB] = {tot_lo & 0xFFFF, tot_lo >> 16, tot_hi & 0xFFFF, tot_hi >> 16};
+        bool over = false;
+#pragma unroll
+        for (uint32_t q = 0; q < LI_SUB; q++)
+            if (tile0 + q < n_tiles) { tile_cnt[tile0 + q] = tot[q]; over |= tot[q] > LL_CAP; }
+        if (over) atomicOr(&info->index_overflow, 1u);
+    }
 #pragma unroll
     for (uint32_t q = 0; q < LI_SUB; q++) {
         if (!c[q]) continue; // (tiles at or beyond n_tiles are empty)
-        uint32_t idx = tile_off[tile0 + q] + sub_excl[q];
+        uint32_t idx = LOCAL ? sub_excl[q] : tile_off[tile0 + q] + sub_excl[q];
         const uint32_t off = base + q * FQZ_TILE + 16 * t;
         const uint32_t prev_b = t ? (uint32_t)(edge[q][t] >> 8) : (q ? (uint32_t)(edge[q ? q - 1 : 0][256] >> 8) : s_ext[0]);
         const uint32_t next_b = t < 255 ? (uint32_t)(edge[q][t + 2] & 0xFF) : (q + 1 < LI_SUB ? (uint32_t)(edge[q + 1 < LI_SUB ? q + 1 : q][1] & 0xFF) : s_ext[1]);
@@ -214,12 +232,51 @@ __global__ __launch_bounds__(256) void k_line_starts(const uint8_t *__restrict__
                 const uint32_t b = (uint32_t)bit >> 3;
                 const uint32_t before = b ? (w[q][k] >> (8 * b - 8)) & 0xFF : (k ? w[q][k ? k - 1 : 0] >> 24 : prev_b);
                 const uint32_t after = b < 3 ? (w[q][k] >> (8 * b + 8)) & 0xFF : (k < 3 ? w[q][k < 3 ? k + 1 : 3] & 0xFF : next_b);
-                idx++;
-                if (idx <= line_cap) {
-                    ls[idx] = off + 4 * k + b + 1; // line idx starts after newline idx
-                    lf[idx] = (uint8_t)((before == '\r' ? 1 : 0) | (after == '@' ? 2 : after == '+' ? 4 : 0));
+                const uint8_t fl = (uint8_t)((before == '\r' ? 1 : 0) | (after == '@' ? 2 : after == '+' ? 4 : 0));
+                if (LOCAL) {
+                    if (idx < LL_CAP) {
+                        lsl[(size_t)(tile0 + q) * LL_CAP + idx] = off + 4 * k + b + 1;
+                        lfl[(size_t)(tile0 + q) * LL_CAP + idx] = fl;
+                    }
+                    idx++;
+                } else {
+                    idx++;
+                    if (idx <= line_cap) {
+                        ls[idx] = off + 4 * k + b + 1; // line idx starts after newline idx
+                        lf[idx] = fl;
+                    }
                 }
             }
+        }
+    }
+}
+
+// tile-local line entries -> ls / lf: entry j of a tile is newline tile_off[tile] + j + 1 of the text.  A workgroup takes
+// 16 tiles and a thread one global entry at a time, so the writes are dense; the tile of an entry comes from a 4-step
+// search over the workgroup's 17 offsets.
+#define LG_TILES 16u
+__global__ __launch_bounds__(256) void k_line_gather(const uint32_t *__restrict__ tile_off, uint32_t n_tiles, const uint32_t *__restrict__ lsl,
+                                                     const uint8_t *__restrict__ lfl, uint32_t *__restrict__ ls, uint8_t *__restrict__ lf, uint32_t line_cap)
+{
+    __shared__ uint32_t so[LG_TILES + 1];
+    const uint32_t t0 = blockIdx.x * LG_TILES;
+    if (threadIdx.x <= LG_TILES) {
+        const uint32_t i = t0 + threadIdx.x;
+        so[threadIdx.x] = tile_off[i < n_tiles ? i : n_tiles];
+    }
+    __syncthreads();
+    const uint32_t first = so[0], total = so[LG_TILES] - first;
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        const uint32_t g = first + e; // newline g + 1 of the text
+        uint32_t k = 0;
+        if (so[k + 8] <= g) k += 8;
+        if (so[k + 4] <= g) k += 4;
+        if (so[k + 2] <= g) k += 2;
+        if (so[k + 1] <= g) k += 1;
+        const uint32_t j = g - so[k];
+        if (j < LL_CAP && g < line_cap) {
+            ls[g + 1] = lsl[(size_t)(t0 + k) * LL_CAP + j];
+            lf[g + 1] = lfl[(size_t)(t0 + k) * LL_CAP + j];
         }
     }
 }
@@ -233,7 +290,7 @@ __global__ void k_setup_records(EncInfo *info, const uint32_t *tile_off, uint32_
     if (threadIdx.x || blockIdx.x) return;
     uint32_t n_lines = tile_off[n_tiles];
     info->n_lines = n_lines;
-    if (n_lines > line_cap) { info->status = FQZ_E_TOO_LARGE; info->n_rec = 0; info->n_blocks = 0; return; }
+    if (n_lines > line_cap || info->index_overflow) { info->status = FQZ_E_TOO_LARGE; info->n_rec = 0; info->n_blocks = 0; return; }
     uint32_t total = n_lines / 4;
     uint32_t n_rec = final_batch ? total : (total / rpb) * rpb;
     uint32_t n_blocks = (n_rec + rpb - 1) / rpb;
@@ -972,7 +1029,10 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
     if ((rc = e.arena.ensure(e.arena_cap + 64))) return rc;
     if ((rc = e.npos.ensure(e.npos_cap + 64))) return rc;
-    if ((rc = e.slots.ensure((size_t)e.chunk_cap * FQZ_SLOT))) return rc;
+    {
+        const size_t slot_bytes = (size_t)e.chunk_cap * FQZ_SLOT, local_bytes = 5ull * e.n_tiles * LL_CAP + 64; // (see k_line_starts<true>)
+        if ((rc = e.slots.ensure(slot_bytes > local_bytes ? slot_bytes : local_bytes))) return rc;
+    }
     if ((rc = e.csize.ensure(4ull * (2ull * e.chunk_cap + 4)))) return rc; // compressed sizes (scanned in place) | cinfo
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
     if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
@@ -993,10 +1053,19 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.zstate.ensure(8ull * zwords))) return rc;
     unsigned long long *z_tiles = e.zstate.as<unsigned long long>(), *z_npos = z_tiles + zt_tiles, *z_chunks = z_npos + zt_npos, *rs_state = z_chunks + zt_chunks;
     hipLaunchKernelGGL(k_init, dim3((zwords + 255) / 256 < 64 ? (zwords + 255) / 256 : 64), dim3(256), 0, st, info, qual_encoding, z_tiles, zwords);
-    if (e.n_tiles) {
+    if (e.n_tiles && !e.two_pass_index) {
+        // the tile-local line tables borrow the chunk slots, which nothing uses before k_entropy
+        uint32_t *lsl = (uint32_t *)slots;
+        uint8_t *lfl = slots + 4ull * e.n_tiles * LL_CAP;
+        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts<true>, dim3((e.n_tiles + LI_SUB - 1) / LI_SUB), dim3(256), 0, st, d_text, n, e.n_tiles,
+                                                        (const uint32_t *)nullptr, ls, lf, e.line_cap, lsl, lfl, tile, info));
+        if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, z_tiles))) return rc;
+        PROF(ctx, st, "k_line_gather", hipLaunchKernelGGL(k_line_gather, dim3((e.n_tiles + LG_TILES - 1) / LG_TILES), dim3(256), 0, st, tile, e.n_tiles, lsl, lfl, ls, lf, e.line_cap));
+    } else if (e.n_tiles) {
         PROF(ctx, st, "k_count_nl", hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile));
         if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, z_tiles))) return rc;
-        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts, dim3((e.n_tiles + LI_SUB - 1) / LI_SUB), dim3(256), 0, st, d_text, n, e.n_tiles, tile, ls, lf, e.line_cap));
+        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts<false>, dim3((e.n_tiles + LI_SUB - 1) / LI_SUB), dim3(256), 0, st, d_text, n, e.n_tiles, tile, ls, lf,
+                                                        e.line_cap, (uint32_t *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, info));
     } else {
         HIP_TRY(hipMemsetAsync(tile, 0, 8, st));
         HIP_TRY(hipMemsetAsync(ls, 0, 8, st));
@@ -1048,6 +1117,11 @@ int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uin
         res->qual_encoding = hi->qual_off == 64 ? FQZ_ENCODING_PHRED64 : FQZ_ENCODING_PHRED33;
         res->n_chunks = hi->n_chunks;
         for (int s = 0; s < FQZ_NS; s++) { res->stream_raw[s] = hi->stream_raw[s]; res->stream_comp[s] = hi->stream_comp[s]; }
+    }
+    if (hi->status == FQZ_E_TOO_LARGE && hi->index_overflow && !e.two_pass_index) {
+        // a tile with more lines than a tile-local slot holds: this context indexes with the two-pass path from now on
+        e.two_pass_index = true;
+        return FQZ_E_TOO_LARGE;
     }
     if (hi->status == FQZ_E_TOO_LARGE && hi->n_lines > e.line_cap) {
         // more lines than the optimistic capacity: remember the exact need so that a relaunch fits

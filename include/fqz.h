@@ -154,7 +154,11 @@ int fqz_encode_batch_dev(fqz_ctx *ctx, const uint8_t *d_fastq, size_t n_bytes, u
                          void *stream);
 
 /* Asynchronous halves of the above for benchmarking / overlap: launch enqueues
- * every kernel on `stream` without a host sync; finish waits and fills `res`. */
+ * every kernel on `stream` without a host sync; finish waits and fills `res`.
+ * finish returns FQZ_E_TOO_LARGE when the text has more (or much shorter)
+ * lines than the workspace was sized for; it has then resized the context,
+ * and the same launch + finish succeeds when repeated (at most twice;
+ * fqz_encode_batch_dev does this by itself). */
 int fqz_encode_batch_launch(fqz_ctx *ctx, const uint8_t *d_fastq, size_t n_bytes, uint32_t records_per_block,
                             int qual_encoding, uint32_t flags, uint8_t *d_out, size_t out_cap, void *stream);
 int fqz_encode_batch_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uint64_t *block_len,
