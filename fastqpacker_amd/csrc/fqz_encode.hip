@@ -677,10 +677,13 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
             piece_locate(pm_iq, iq, pq, on ? p : 0, &i, &k);
             const uint32_t Li = (uint32_t)__shfl((int)L, (int)i, WAVE), src = (uint32_t)__shfl((int)s_qual, (int)i, WAVE);
             const uint32_t dst = (uint32_t)__shfl((int)d_qual, (int)i, WAVE);
+            // the byte before a piece is the last byte of the previous lane's piece (same read, k - 1); only lane 0 has to
+            // fetch it from the text
+            uint32_t x[4] = {0, 0, 0, 0}, w[4];
+            if (on) load_piece(text, src + 16 * k, n_text, x);
+            const uint32_t left = (uint32_t)__shfl_up((int)(x[3] >> 24), 1, WAVE);
             if (on) {
-                uint32_t x[4], w[4];
-                uint32_t prev = k ? text[src + 16 * k - 1] : qoff;
-                load_piece(text, src + 16 * k, n_text, x);
+                uint32_t prev = k ? (lane ? left : text[src + 16 * k - 1]) : qoff;
 #pragma unroll
                 for (int q = 0; q < 4; q++) { w[q] = sub_bytes(x[q], (x[q] << 8) | (prev & 0xFF)); prev = x[q] >> 24; }
                 store_piece(arena + dst + 16 * k, w, Li - 16 * k < 16 ? Li - 16 * k : 16);
