@@ -160,17 +160,9 @@ __global__ __launch_bounds__(256) void k_count_nl(const uint8_t *text, uint32_t 
 // newline counts are scanned together, packed 2 x 16 bits, and every tile adds its own base from the tile scan.
 // The bytes either side of a newline come from registers (neighbouring threads' edge bytes through LDS).
 #define LI_SUB 4u
-//
-// LOCAL (the default path): the text is read ONCE.  Nothing is known about the tiles before this one, so a tile's
-// entries go to its own slot of LL_CAP entries (lsl / lfl, tile-local index), its newline count to tile_cnt; after
-// the scan of the counts k_line_gather moves the entries to their global places (57 MB instead of a second pass over
-// the text to count newlines first).  A tile with more than LL_CAP lines (lines under 8 bytes on average) raises
-// info->index_overflow and the batch is redone with the two-pass path (k_count_nl, scan, this kernel with LOCAL = false).
-#define LL_CAP 512u
-template <bool LOCAL>
+// Two-pass index (fallback, see k_line_local): needs the scanned per-tile newline counts (k_count_nl + k_scan) first.
 __global__ __launch_bounds__(256) void k_line_starts(const uint8_t *__restrict__ text, uint32_t n, uint32_t n_tiles, const uint32_t *__restrict__ tile_off,
-                                                     uint32_t *__restrict__ ls, uint8_t *__restrict__ lf, uint32_t line_cap,
-                                                     uint32_t *__restrict__ lsl, uint8_t *__restrict__ lfl, uint32_t *__restrict__ tile_cnt, EncInfo *info)
+                                                     uint32_t *__restrict__ ls, uint8_t *__restrict__ lf, uint32_t line_cap)
 {
     __shared__ uint32_t sh_lo[4], sh_hi[4], s_ext[2];
     __shared__ uint16_t edge[LI_SUB][258]; // [q][t + 1] = first byte | last byte << 8 of thread t's 16 bytes of tile q
@@ -207,19 +199,10 @@ __global__ __launch_bounds__(256) void k_line_starts(const uint8_t *__restrict__
         ls[0] = 0;
         lf[0] = (uint8_t)(n ? (((w[0][0] & 0xFF) == '@' ? 1 : (w[0][0] & 0xFF) == '+' ? 2 : 0) << 1) : 0);
     }
-    if (LOCAL && t == 0) {
-        const uint32_t tot_lo = sh_lo[0] + sh_lo[1] + sh_lo[2] + sh_lo[3], tot_hi = sh_hi[0] + sh_hi[1] + sh_hi[2] + sh_hi[3];
-        const uint32_t tot[LI_SUB] = {tot_lo & 0xFFFF, tot_lo >> 16, tot_hi & 0xFFFF, tot_hi >> 16};
-        bool over = false;
-#pragma unroll
-        for (uint32_t q = 0; q < LI_SUB; q++)
-            if (tile0 + q < n_tiles) { tile_cnt[tile0 + q] = tot[q]; over |= tot[q] > LL_CAP; }
-        if (over) atomicOr(&info->index_overflow, 1u);
-    }
 #pragma unroll
     for (uint32_t q = 0; q < LI_SUB; q++) {
         if (!c[q]) continue; // (tiles at or beyond n_tiles are empty)
-        uint32_t idx = LOCAL ? sub_excl[q] : tile_off[tile0 + q] + sub_excl[q];
+        uint32_t idx = tile_off[tile0 + q] + sub_excl[q];
         const uint32_t off = base + q * FQZ_TILE + 16 * t;
         const uint32_t prev_b = t ? (uint32_t)(edge[q][t] >> 8) : (q ? (uint32_t)(edge[q ? q - 1 : 0][256] >> 8) : s_ext[0]);
         const uint32_t next_b = t < 255 ? (uint32_t)(edge[q][t + 2] & 0xFF) : (q + 1 < LI_SUB ? (uint32_t)(edge[q + 1 < LI_SUB ? q + 1 : q][1] & 0xFF) : s_ext[1]);
@@ -232,22 +215,86 @@ __global__ __launch_bounds__(256) void k_line_starts(const uint8_t *__restrict__
                 const uint32_t b = (uint32_t)bit >> 3;
                 const uint32_t before = b ? (w[q][k] >> (8 * b - 8)) & 0xFF : (k ? w[q][k ? k - 1 : 0] >> 24 : prev_b);
                 const uint32_t after = b < 3 ? (w[q][k] >> (8 * b + 8)) & 0xFF : (k < 3 ? w[q][k < 3 ? k + 1 : 3] & 0xFF : next_b);
-                const uint8_t fl = (uint8_t)((before == '\r' ? 1 : 0) | (after == '@' ? 2 : after == '+' ? 4 : 0));
-                if (LOCAL) {
-                    if (idx < LL_CAP) {
-                        lsl[(size_t)(tile0 + q) * LL_CAP + idx] = off + 4 * k + b + 1;
-                        lfl[(size_t)(tile0 + q) * LL_CAP + idx] = fl;
-                    }
-                    idx++;
-                } else {
-                    idx++;
-                    if (idx <= line_cap) {
-                        ls[idx] = off + 4 * k + b + 1; // line idx starts after newline idx
-                        lf[idx] = fl;
-                    }
+                idx++;
+                if (idx <= line_cap) {
+                    ls[idx] = off + 4 * k + b + 1; // line idx starts after newline idx
+                    lf[idx] = (uint8_t)((before == '\r' ? 1 : 0) | (after == '@' ? 2 : after == '+' ? 4 : 0));
                 }
             }
         }
+    }
+}
+
+
+// The default path reads the text ONCE.  Nothing is known about the tiles before this one, so a tile's entries go to its
+// own slot of LL_CAP entries (lsl / lfl, tile-local index) and its newline count to tile_cnt; after the scan of the
+// counts k_line_gather moves the entries to their global places (57 MB instead of a second pass over the text to count
+// newlines first).  A tile with more than LL_CAP lines (lines under 8 bytes on average) raises info->index_overflow and
+// the batch is redone with the two-pass path (k_count_nl, scan, k_line_starts).
+// One WAVE per 4 KiB tile (four rows of 64 x 16 bytes), no workgroup barrier: the per-lane newline counts of the four
+// rows are scanned together (packed 2 x 16 bits), then every newline's tile-local position is dropped into a list in
+// LDS (a short divergent loop: nothing but find-first-set and a 2-byte store), and the list - ~47 entries for 150 bp
+// reads - is turned into (line start, flags) entries by consecutive lanes: dense stores, and the bytes either side of
+// the newline are two L1-hot byte loads.
+#define LL_CAP 512u
+__global__ __launch_bounds__(256) void k_line_local(const uint8_t *__restrict__ text, uint32_t n, uint32_t n_tiles, uint32_t *__restrict__ ls,
+                                                    uint8_t *__restrict__ lf, uint32_t *__restrict__ lsl, uint8_t *__restrict__ lfl,
+                                                    uint32_t *__restrict__ tile_cnt, EncInfo *info)
+{
+    __shared__ uint16_t s_pos[4][LL_CAP];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t tile = blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return; // (whole waves leave; the kernel has no workgroup barrier)
+    const uint32_t tbase = tile * FQZ_TILE;
+    uint32_t m[4][4], c[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint4 v = load_text16(text, tbase + q * 1024 + 16 * lane, n);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        c[q] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { m[q][k] = zero_bytes(w[k] ^ 0x0A0A0A0Au); c[q] += __popc(m[q][k]); }
+        if (tile == 0 && q == 0 && lane == 0) {
+            ls[0] = 0;
+            lf[0] = (uint8_t)(n ? (((v.x & 0xFF) == '@' ? 1 : (v.x & 0xFF) == '+' ? 2 : 0) << 1) : 0);
+        }
+    }
+    // exclusive prefix of the counts in text order (row-major), packed 2 x 16 bits (a row holds <= 1024 newlines)
+    const uint32_t lo = c[0] | (c[1] << 16), hi = c[2] | (c[3] << 16);
+    const uint32_t incl_lo = wave_incl_scan(lo), incl_hi = wave_incl_scan(hi);
+    const uint32_t tot_lo = (uint32_t)__builtin_amdgcn_readlane((int)incl_lo, 63), tot_hi = (uint32_t)__builtin_amdgcn_readlane((int)incl_hi, 63);
+    const uint32_t rb1 = tot_lo & 0xFFFF, rb2 = rb1 + (tot_lo >> 16), rb3 = rb2 + (tot_hi & 0xFFFF), total = rb3 + (tot_hi >> 16);
+    const uint32_t ex_lo = incl_lo - lo, ex_hi = incl_hi - hi;
+    const uint32_t excl[4] = {ex_lo & 0xFFFF, rb1 + (ex_lo >> 16), rb2 + (ex_hi & 0xFFFF), rb3 + (ex_hi >> 16)};
+    if (lane == 0) {
+        tile_cnt[tile] = total;
+        if (total > LL_CAP) atomicOr(&info->index_overflow, 1u);
+    }
+    // ---- tile-local position of every newline -> list
+    uint16_t *list = s_pos[wave];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        uint32_t idx = excl[q];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t mk = m[q][k];
+            while (mk) {
+                const uint32_t bit = (uint32_t)__ffs(mk) - 1; // 7, 15, 23, 31
+                mk &= mk - 1;
+                if (idx < LL_CAP) list[idx] = (uint16_t)(q * 1024 + 16 * lane + 4 * k + (bit >> 3));
+                idx++;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- list -> entries: line j + 1 of the tile starts after newline j; flags as in k_line_starts
+    const uint32_t cnt = total < LL_CAP ? total : LL_CAP;
+    for (uint32_t j = lane; j < cnt; j += 64) {
+        const uint32_t p = tbase + list[j];
+        const uint32_t before = p ? text[p - 1] : 0u, after = p + 1 < n ? text[p + 1] : 0u;
+        lsl[(size_t)tile * LL_CAP + j] = p + 1;
+        lfl[(size_t)tile * LL_CAP + j] = (uint8_t)((before == '\r' ? 1 : 0) | (after == '@' ? 2 : after == '+' ? 4 : 0));
     }
 }
 
@@ -1033,7 +1080,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.arena.ensure(e.arena_cap + 64))) return rc;
     if ((rc = e.npos.ensure(e.npos_cap + 64))) return rc;
     {
-        const size_t slot_bytes = (size_t)e.chunk_cap * FQZ_SLOT, local_bytes = 5ull * e.n_tiles * LL_CAP + 64; // (see k_line_starts<true>)
+        const size_t slot_bytes = (size_t)e.chunk_cap * FQZ_SLOT, local_bytes = 5ull * e.n_tiles * LL_CAP + 64; // (see k_line_local)
         if ((rc = e.slots.ensure(slot_bytes > local_bytes ? slot_bytes : local_bytes))) return rc;
     }
     if ((rc = e.csize.ensure(4ull * (2ull * e.chunk_cap + 4)))) return rc; // compressed sizes (scanned in place) | cinfo
@@ -1060,15 +1107,13 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         // the tile-local line tables borrow the chunk slots, which nothing uses before k_entropy
         uint32_t *lsl = (uint32_t *)slots;
         uint8_t *lfl = slots + 4ull * e.n_tiles * LL_CAP;
-        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts<true>, dim3((e.n_tiles + LI_SUB - 1) / LI_SUB), dim3(256), 0, st, d_text, n, e.n_tiles,
-                                                        (const uint32_t *)nullptr, ls, lf, e.line_cap, lsl, lfl, tile, info));
+        PROF(ctx, st, "k_line_local", hipLaunchKernelGGL(k_line_local, dim3((e.n_tiles + 3) / 4), dim3(256), 0, st, d_text, n, e.n_tiles, ls, lf, lsl, lfl, tile, info));
         if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, z_tiles))) return rc;
         PROF(ctx, st, "k_line_gather", hipLaunchKernelGGL(k_line_gather, dim3((e.n_tiles + LG_TILES - 1) / LG_TILES), dim3(256), 0, st, tile, e.n_tiles, lsl, lfl, ls, lf, e.line_cap));
     } else if (e.n_tiles) {
         PROF(ctx, st, "k_count_nl", hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile));
         if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, z_tiles))) return rc;
-        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts<false>, dim3((e.n_tiles + LI_SUB - 1) / LI_SUB), dim3(256), 0, st, d_text, n, e.n_tiles, tile, ls, lf,
-                                                        e.line_cap, (uint32_t *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, info));
+        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts, dim3((e.n_tiles + LI_SUB - 1) / LI_SUB), dim3(256), 0, st, d_text, n, e.n_tiles, tile, ls, lf, e.line_cap));
     } else {
         HIP_TRY(hipMemsetAsync(tile, 0, 8, st));
         HIP_TRY(hipMemsetAsync(ls, 0, 8, st));
