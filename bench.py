@@ -208,7 +208,8 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")))
-            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+            if abs(in_bytes - pmc.get("batch_bytes", in_bytes)) <= 0.01 * in_bytes:  # counters were taken on the default batch
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
         except Exception:
             pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

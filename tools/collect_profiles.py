@@ -29,10 +29,13 @@ for tag, key in (("fetch", "FETCH_SIZE_KiB"), ("write", "WRITE_SIZE_KiB")):
         for k, (v, n) in agg.items():
             pmc.setdefault(k, {})[key] = round(v / n, 1)
 # gfx950: FETCH_SIZE reports half of a wide coalesced stream (16 B per lane, aligned; MI355X_MICROARCH.md, HBM section).
-# Calibrated here on known byte counts: k_count_nl / k_line_index read the text exactly once (factor 2 confirmed);
+# Calibrated here on known byte counts: k_line_local (and k_count_nl of the two-pass path) read the text exactly once (factor 2 confirmed);
 # k_entropy reads the 646 MB of pre-entropy streams twice, histogram pass and encode pass (2 x 646 MB = 1.29 GB expected, 2 x FETCH_SIZE = 1.38 GB reported); k_split gathers unaligned 16-byte pieces
 # (64-B requests) and reads text + line index + record offsets = 1.10 GB, which FETCH_SIZE reports as is (factor 1).
-FETCH_FACTOR = {"k_split": 1}
+# k_line_local: the same aligned stream over the text (485.7 k KiB as FETCH_SIZE counts it, known from k_count_nl on the same
+# batch, i.e. 971 k KiB real) plus single-byte loads either side of every newline that missed L2 (the rest of its FETCH_SIZE,
+# counted in full): (2 * 485.7 + 298.2) / 783.9 = 1.62.
+FETCH_FACTOR = {"k_split": 1, "k_line_local": 1.62}
 for k, d in pmc.items():
     f = FETCH_FACTOR.get(k, 2)
     d["fetch_factor"] = f
@@ -40,9 +43,10 @@ for k, d in pmc.items():
 doc = {"_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, bench.py --steps 2, 0.99 GB batch). "
                    "Units: KiB per launch as reported. On gfx950 FETCH_SIZE counts half of a wide coalesced stream "
                    "(MI355X_MICROARCH.md, HBM section): hbm_bytes = (fetch_factor*FETCH_SIZE + WRITE_SIZE) * 1024 with fetch_factor 2 "
-                   "for the aligned 16-B-per-lane streams (calibrated: k_count_nl reads the 994.6 MB text exactly once, k_entropy the "
+                   "for the aligned 16-B-per-lane streams (calibrated: k_line_local / k_count_nl read the 994.6 MB text exactly once, k_entropy the "
                    "646 MB of pre-entropy streams, which it reads twice) and 1 for k_split, whose unaligned 16-byte gathers are tallied exactly (known input "
                    "1.10 GB = text + line index + record offsets). Decode kernels use factor 2 uncalibrated.",
+       "batch_bytes": 994586598,  # bench.py default workload (--bytes 1e9 cut on a record boundary): the figures hold for this batch only
        "kernels": dict(sorted(pmc.items()))}
 json.dump(doc, open(os.path.join(dst, "pmc_hbm_traffic.json"), "w"), indent=1)
 lines.append("")
