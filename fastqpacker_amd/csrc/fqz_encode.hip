@@ -673,17 +673,26 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
         const PieceMap pm_iq = piece_map_make(pq, iq), pm_ih = piece_map_make(ph, ih), pm_ip = piece_map_make(pp, ip);
         const uint32_t Tq = (uint32_t)RL(iq, 63), Th = (uint32_t)RL(ih, 63), Tp = (uint32_t)RL(ip, 63);
 
-        // ---- bases: 16 bases -> 4 packed bytes (sequence.go:139-184); N counts go to E[nPos] (compress.go:477-488)
+        // ---- bases and qualities share the piece map (both lines of a record have L bytes): one pass, both loads in flight.
+        // bases: 16 bases -> 4 packed bytes (sequence.go:139-184); N counts go to E[nPos] (compress.go:477-488)
+        // quality: q'[0] = q[0]-off, q'[j] = q[j]-q[j-1], restarting per record (quality.go:53-103)
         for (uint32_t base = 0; base < Tq; base += WAVE) {
             const uint32_t p = base + lane;
             const bool on = p < Tq;
             uint32_t i, k;
             piece_locate(pm_iq, iq, pq, on ? p : 0, &i, &k);
-            const uint32_t Li = (uint32_t)__shfl((int)L, (int)i, WAVE), src = (uint32_t)__shfl((int)s_seq, (int)i, WAVE);
-            const uint32_t dst = (uint32_t)__shfl((int)d_seq, (int)i, WAVE);
+            const uint32_t Li = (uint32_t)__shfl((int)L, (int)i, WAVE);
+            const uint32_t src = (uint32_t)__shfl((int)s_seq, (int)i, WAVE), srcq = (uint32_t)__shfl((int)s_qual, (int)i, WAVE);
+            const uint32_t dst = (uint32_t)__shfl((int)d_seq, (int)i, WAVE), dstq = (uint32_t)__shfl((int)d_qual, (int)i, WAVE);
+            uint32_t x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
             if (on) {
-                uint32_t x[4];
                 load_piece(text, src + 16 * k, n_text, x);
+                load_piece(text, srcq + 16 * k, n_text, y);
+            }
+            // the byte before a quality piece is the last byte of the previous lane's piece (same read, k - 1); only lane 0
+            // has to fetch it from the text
+            const uint32_t left = (uint32_t)__shfl_up((int)(y[3] >> 24), 1, WAVE);
+            if (on) {
                 const uint32_t have = Li - 16 * k < 16 ? Li - 16 * k : 16;
                 uint32_t out = 0, nn = 0, beyond = 0;
 #pragma unroll
@@ -714,26 +723,11 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
                 }
                 if (beyond) report_error(info, g * 64 + i, 4, FQZ_E_LONG_N);
                 if (nn) atomicAdd(&Enpos[g * 64 + i], 2 * nn);
-            }
-        }
-        // ---- quality: q'[0] = q[0]-off, q'[j] = q[j]-q[j-1], restarting per record (quality.go:53-103)
-        for (uint32_t base = 0; base < Tq; base += WAVE) {
-            const uint32_t p = base + lane;
-            const bool on = p < Tq;
-            uint32_t i, k;
-            piece_locate(pm_iq, iq, pq, on ? p : 0, &i, &k);
-            const uint32_t Li = (uint32_t)__shfl((int)L, (int)i, WAVE), src = (uint32_t)__shfl((int)s_qual, (int)i, WAVE);
-            const uint32_t dst = (uint32_t)__shfl((int)d_qual, (int)i, WAVE);
-            // the byte before a piece is the last byte of the previous lane's piece (same read, k - 1); only lane 0 has to
-            // fetch it from the text
-            uint32_t x[4] = {0, 0, 0, 0}, w[4];
-            if (on) load_piece(text, src + 16 * k, n_text, x);
-            const uint32_t left = (uint32_t)__shfl_up((int)(x[3] >> 24), 1, WAVE);
-            if (on) {
-                uint32_t prev = k ? (lane ? left : text[src + 16 * k - 1]) : qoff;
+                uint32_t w[4];
+                uint32_t prev = k ? (lane ? left : text[srcq + 16 * k - 1]) : qoff;
 #pragma unroll
-                for (int q = 0; q < 4; q++) { w[q] = sub_bytes(x[q], (x[q] << 8) | (prev & 0xFF)); prev = x[q] >> 24; }
-                store_piece(arena + dst + 16 * k, w, Li - 16 * k < 16 ? Li - 16 * k : 16);
+                for (int q = 0; q < 4; q++) { w[q] = sub_bytes(y[q], (y[q] << 8) | (prev & 0xFF)); prev = y[q] >> 24; }
+                store_piece(arena + dstq + 16 * k, w, have);
             }
         }
         // ---- header and plus payloads (without '@' / '+'), after their u16 length
