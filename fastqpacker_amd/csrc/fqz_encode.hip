@@ -676,28 +676,33 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
         // ---- bases and qualities share the piece map (both lines of a record have L bytes): one pass, both loads in flight.
         // bases: 16 bases -> 4 packed bytes (sequence.go:139-184); N counts go to E[nPos] (compress.go:477-488)
         // quality: q'[0] = q[0]-off, q'[j] = q[j]-q[j-1], restarting per record (quality.go:53-103)
-        for (uint32_t base = 0; base < Tq; base += WAVE) {
-            const uint32_t p = base + lane;
-            const bool on = p < Tq;
-            uint32_t i, k;
-            piece_locate(pm_iq, iq, pq, on ? p : 0, &i, &k);
-            const uint32_t Li = (uint32_t)__shfl((int)L, (int)i, WAVE);
-            const uint32_t src = (uint32_t)__shfl((int)s_seq, (int)i, WAVE), srcq = (uint32_t)__shfl((int)s_qual, (int)i, WAVE);
-            const uint32_t dst = (uint32_t)__shfl((int)d_seq, (int)i, WAVE), dstq = (uint32_t)__shfl((int)d_qual, (int)i, WAVE);
-            uint32_t x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
-            if (on) {
-                load_piece(text, src + 16 * k, n_text, x);
-                load_piece(text, srcq + 16 * k, n_text, y);
+        struct PieceJob { bool on; uint32_t i, k, have, dst, dstq, srcq, x[4], y[4]; };
+        auto fetch = [&](uint32_t p, PieceJob &J) { // every lane of the wave calls this
+            J.on = p < Tq;
+            piece_locate(pm_iq, iq, pq, J.on ? p : 0, &J.i, &J.k);
+            const uint32_t Li = (uint32_t)__shfl((int)L, (int)J.i, WAVE);
+            const uint32_t src = (uint32_t)__shfl((int)s_seq, (int)J.i, WAVE);
+            J.srcq = (uint32_t)__shfl((int)s_qual, (int)J.i, WAVE);
+            J.dst = (uint32_t)__shfl((int)d_seq, (int)J.i, WAVE);
+            J.dstq = (uint32_t)__shfl((int)d_qual, (int)J.i, WAVE);
+            J.have = Li - 16 * J.k < 16 ? Li - 16 * J.k : 16;
+#pragma unroll
+            for (int q = 0; q < 4; q++) J.x[q] = J.y[q] = 0;
+            if (J.on) {
+                load_piece(text, src + 16 * J.k, n_text, J.x);
+                load_piece(text, J.srcq + 16 * J.k, n_text, J.y);
             }
+        };
+        auto finish = [&](PieceJob &J) {
             // the byte before a quality piece is the last byte of the previous lane's piece (same read, k - 1); only lane 0
             // has to fetch it from the text
-            const uint32_t left = (uint32_t)__shfl_up((int)(y[3] >> 24), 1, WAVE);
-            if (on) {
-                const uint32_t have = Li - 16 * k < 16 ? Li - 16 * k : 16;
+            const uint32_t left = (uint32_t)__shfl_up((int)(J.y[3] >> 24), 1, WAVE);
+            if (J.on) {
+                const uint32_t have = J.have, k = J.k;
                 uint32_t out = 0, nn = 0, beyond = 0;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    uint32_t v = x[q], in_read = 0x80808080u;
+                    uint32_t v = J.x[q], in_read = 0x80808080u;
                     if (have < 4u * q + 4) { // bytes past the read pack as 0
                         const uint32_t hv = have > 4u * q ? have - 4u * q : 0;
                         v = hv ? v & ((1u << (8 * hv)) - 1) : 0;
@@ -715,20 +720,29 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
                     }
                 }
                 const uint32_t nb = (have + 3) >> 2;
-                uint8_t *o = arena + dst + 4 * k;
+                uint8_t *o = arena + J.dst + 4 * k;
                 if (nb == 4) store_u32_unaligned(o, out);
                 else { // 1..3 packed bytes at the end of a read
                     if (nb & 2) { uint16_t v = (uint16_t)out; __builtin_memcpy(o, &v, 2); }
                     if (nb & 1) o[nb & 2] = (uint8_t)(out >> (8 * (nb & 2)));
                 }
-                if (beyond) report_error(info, g * 64 + i, 4, FQZ_E_LONG_N);
-                if (nn) atomicAdd(&Enpos[g * 64 + i], 2 * nn);
+                if (beyond) report_error(info, g * 64 + J.i, 4, FQZ_E_LONG_N);
+                if (nn) atomicAdd(&Enpos[g * 64 + J.i], 2 * nn);
                 uint32_t w[4];
-                uint32_t prev = k ? (lane ? left : text[srcq + 16 * k - 1]) : qoff;
+                uint32_t prev = k ? (lane ? left : text[J.srcq + 16 * k - 1]) : qoff;
 #pragma unroll
-                for (int q = 0; q < 4; q++) { w[q] = sub_bytes(y[q], (y[q] << 8) | (prev & 0xFF)); prev = y[q] >> 24; }
-                store_piece(arena + dstq + 16 * k, w, have);
+                for (int q = 0; q < 4; q++) { w[q] = sub_bytes(J.y[q], (J.y[q] << 8) | (prev & 0xFF)); prev = J.y[q] >> 24; }
+                store_piece(arena + J.dstq + 16 * k, w, have);
             }
+        };
+        // two rounds of 64 pieces per trip: four loads per lane in flight before the first one is used
+        for (uint32_t base = 0; base < Tq; base += 2 * WAVE) {
+            PieceJob A, B;
+            fetch(base + lane, A);
+            const bool two = base + WAVE < Tq;
+            if (two) fetch(base + WAVE + lane, B);
+            finish(A);
+            if (two) finish(B);
         }
         // ---- header and plus payloads (without '@' / '+'), after their u16 length
         for (uint32_t base = 0; base < Th; base += WAVE) {
