@@ -102,6 +102,7 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     DevBuf *db[] = {&d.info, &d.blocks, &d.chunks, &d.streams, &d.rec, &d.partials, &d.tables, &d.lz_scratch};
     for (DevBuf *b : db) b->release();
     d.h_info.release(); d.h_blocks.release();
+    if (d.side) { (void)hipStreamSynchronize(d.side); (void)hipStreamDestroy(d.side); (void)hipEventDestroy(d.ev_fork); (void)hipEventDestroy(d.ev_join); }
     c->prof.collect();
     for (hipEvent_t ev : c->prof.pool) (void)hipEventDestroy(ev);
     c->d_in.release(); c->d_out.release(); c->h_stage.release();

@@ -94,6 +94,8 @@ struct DecState {
     uint8_t *d_out = nullptr;
     size_t out_cap = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;            // bases + qualities are entropy-decoded here while the record walks run on `stream`
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool in_flight = false;
     DevBuf info, blocks, chunks, streams, rec, partials, tables, lz_scratch;
     PinnedBuf h_info, h_blocks;
