@@ -64,7 +64,8 @@ struct EncState {
     size_t out_cap = 0;
     hipStream_t stream = nullptr;
     bool in_flight = false;
-    bool two_pass_index = false; // set once a batch overflowed a tile-local line slot: count newlines first, then index
+    bool two_pass_now = false;   // the launch in flight used the two-pass index
+    uint32_t two_pass_left = 0;  // > 0 after a batch overflowed a tile-local line slot: this many launches count newlines first, then index
     // capacities
     uint32_t n_tiles = 0, line_cap = 0, rec_cap = 0, block_cap = 0, chunk_cap = 0;
     size_t arena_cap = 0, npos_cap = 0;

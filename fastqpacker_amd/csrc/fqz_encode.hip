@@ -1115,7 +1115,10 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if ((rc = e.zstate.ensure(8ull * zwords))) return rc;
     unsigned long long *z_tiles = e.zstate.as<unsigned long long>(), *z_npos = z_tiles + zt_tiles, *z_chunks = z_npos + zt_npos, *rs_state = z_chunks + zt_chunks;
     hipLaunchKernelGGL(k_init, dim3((zwords + 255) / 256 < 64 ? (zwords + 255) / 256 : 64), dim3(256), 0, st, info, qual_encoding, z_tiles, zwords);
-    if (e.n_tiles && !e.two_pass_index) {
+    const bool two_pass = e.two_pass_left > 0; // (the text of the last batches had lines too short for the single-pass index)
+    if (two_pass) e.two_pass_left--;
+    e.two_pass_now = two_pass;
+    if (e.n_tiles && !two_pass) {
         // the tile-local line tables borrow the chunk slots, which nothing uses before k_entropy
         uint32_t *lsl = (uint32_t *)slots;
         uint8_t *lfl = slots + 4ull * e.n_tiles * LL_CAP;
@@ -1178,9 +1181,10 @@ int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uin
         res->n_chunks = hi->n_chunks;
         for (int s = 0; s < FQZ_NS; s++) { res->stream_raw[s] = hi->stream_raw[s]; res->stream_comp[s] = hi->stream_comp[s]; }
     }
-    if (hi->status == FQZ_E_TOO_LARGE && hi->index_overflow && !e.two_pass_index) {
-        // a tile with more lines than a tile-local slot holds: this context indexes with the two-pass path from now on
-        e.two_pass_index = true;
+    if (hi->status == FQZ_E_TOO_LARGE && hi->index_overflow && !e.two_pass_now) {
+        // a tile with more lines than a tile-local slot holds: this batch is redone, and the next ones are done, with the
+        // two-pass index (such inputs come in runs; after 16 launches the single-pass index gets another try)
+        e.two_pass_left = 16;
         return FQZ_E_TOO_LARGE;
     }
     if (hi->status == FQZ_E_TOO_LARGE && hi->n_lines > e.line_cap) {

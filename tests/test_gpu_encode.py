@@ -114,13 +114,14 @@ def test_multi_block_batch_matches_oracle(fq):
 def test_tiny_records_fall_back_to_two_pass_index(fq):
     """Lines of 2 bytes on average: a 4 KiB tile holds ~1800 of them, more than a tile-local slot of the single-pass line
     index (512) and more lines than the optimistic line table; the encoder redoes the batch with the two-pass index and a
-    larger table.  The same context must keep working (on the two-pass path) for ordinary input afterwards."""
+    larger table.  The same context must keep working for ordinary input afterwards (on the two-pass path for the next 16
+    launches, then single-pass again)."""
     import torch
     dev = torch.device("cuda:0")
     ctx = fq.Ctx(0)
     tiny = b"".join(b"@%c\n%c\n+\n%c\n" % (97 + i % 26, b"ACGTN"[i % 5], 33 + i % 40) for i in range(30000))
     normal = make_fastq(3000, seed=77, min_len=100, max_len=151, n_frac=0.01)
-    for text, rpb in ((tiny, 7000), (normal, 1000), (tiny, 7000)):
+    for text, rpb in [(tiny, 7000), (normal, 1000), (tiny, 7000)] + [(normal, 1000)] * 18 + [(tiny, 7000)]:
         t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
         out = torch.empty(len(text) * 4 + (1 << 20), dtype=torch.uint8, device=dev)
         res = fq.compress.encode_batch_dev(t.data_ptr(), t.numel(), out.data_ptr(), out.numel(), records_per_block=rpb, final=True, ctx=ctx)
