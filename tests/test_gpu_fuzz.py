@@ -16,13 +16,16 @@ def fq():
 
 
 def _cases():
-    rng = np.random.default_rng(20240607)
+    # FQZ_FUZZ_N / FQZ_FUZZ_SEED widen the sweep for a one-off soak (e.g. 400 cases with another seed after a kernel change)
+    import os
+    n_cases, seed = int(os.environ.get("FQZ_FUZZ_N", "60")), int(os.environ.get("FQZ_FUZZ_SEED", "20240607"))
+    rng = np.random.default_rng(seed)
     out = []
-    for i in range(60):
+    for i in range(n_cases):
         n = int(rng.choice([1, 2, 3, 7, 63, 64, 65, 127, 300, 1000, 2500]))
         lo = int(rng.choice([0, 1, 4, 15, 16, 17, 35, 63, 64, 100, 151]))
         hi = lo + int(rng.choice([0, 1, 3, 16, 50, 300, 1100]))
-        out.append(dict(n_records=n, seed=1000 + i, min_len=lo, max_len=hi, n_frac=float(rng.choice([0, 0, 0.01, 0.2, 1.0])),
+        out.append(dict(n_records=n, seed=1000 + i + (seed - 20240607) % 1000003, min_len=lo, max_len=hi, n_frac=float(rng.choice([0, 0, 0.01, 0.2, 1.0])),
                         phred=int(rng.choice([33, 33, 64])), plus_payload=bool(rng.integers(0, 2)), crlf=bool(rng.random() < 0.15),
                         block=int(rng.choice([1, 3, 64, 100, 1000, 100000]))))
     return out
