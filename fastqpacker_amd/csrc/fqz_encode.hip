@@ -365,7 +365,9 @@ __device__ __forceinline__ void line_span(const uint8_t *text, const uint32_t *l
 // of a running tile is running or done.  state[tile][column] = flag << 62 | value (1 = tile sum, 2 = inclusive
 // prefix).  Large tiles keep the look-back chain short (the prefix front advances 64 tiles per memory round trip);
 // the record sizes are computed twice (sums, then offsets) rather than kept in 64 registers.
+#ifndef RS_PER
 #define RS_PER 16u
+#endif
 #define RS_TILE (256u * RS_PER)
 #define RS_AGG (1ull << 62)
 #define RS_PREFIX (2ull << 62)
