@@ -758,8 +758,8 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                 else {
                     const int hb = highbit32_d(sp[sn - 1]);
                     const uint32_t total_bits = (sn - 1) * 8 + (uint32_t)hb;
-                    unsigned long long hi = 0, lo = 0;
-                    int avail = 0;            // valid bits in hi:lo
+                    uint32_t b3 = 0, b2 = 0, b1 = 0, b0 = 0; // the bit buffer as four words (b3 on top): a shift is three v_alignbit + one shift
+                    int avail = 0;            // valid bits in b3:b2:b1:b0
                     int byte_pos = (int)sn;   // bytes [0, byte_pos) not fetched yet
                     // a dword that ends at byte_pos: bytes before the stream belong to the same zstd block, always readable
                     auto fetch = [&](uint32_t &w, int &nb) {
@@ -771,20 +771,28 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                     auto merge = [&](uint32_t w, int nb) { // append the top nb bits of w below the valid bits
                         const uint32_t keep = nb == 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> nb);
                         const unsigned long long v = (unsigned long long)(w & keep) << 32; // left-aligned in 64 bits
+                        unsigned long long hi = ((unsigned long long)b3 << 32) | b2, lo = ((unsigned long long)b1 << 32) | b0;
                         if (avail < 64) { hi |= v >> avail; if (avail > 32) lo |= v << (64 - avail); }
                         else lo |= v >> (avail - 64);
+                        b3 = (uint32_t)(hi >> 32); b2 = (uint32_t)hi; b1 = (uint32_t)(lo >> 32); b0 = (uint32_t)lo;
                         avail += nb;
+                    };
+                    auto shift_bits = [&](uint32_t nb) { // 1 <= nb <= 31
+                        const uint32_t sh = 32 - nb;
+                        b3 = __builtin_amdgcn_alignbit(b3, b2, sh);
+                        b2 = __builtin_amdgcn_alignbit(b2, b1, sh);
+                        b1 = __builtin_amdgcn_alignbit(b1, b0, sh);
+                        b0 <<= nb;
                     };
                     { // prime: four dwords
                         uint32_t w[4]; int nb[4];
                         for (int q = 0; q < 4; q++) fetch(w[q], nb[q]);
                         for (int q = 0; q < 4; q++) merge(w[q], nb[q]);
                         const int pad = 8 - hb; // end mark and the zero bits above it
-                        hi = (hi << pad) | (lo >> (64 - pad));
-                        lo <<= pad;
+                        shift_bits((uint32_t)pad);
                         avail -= pad;
                     }
-                    const uint32_t sh1 = 64 - l1b, sh2 = 64 - tl;
+                    const uint32_t sh1 = 32 - l1b, sh2 = 32 - tl;
                     const bool aligned = (((uintptr_t)dst) & 15) == 0;
                     uint8_t *ob = (uint8_t *)obuf + (lane << 2);
                     uint32_t used_bits = 0;
@@ -802,15 +810,14 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
 #pragma unroll
                         for (uint32_t u = 0; u < 4; u++) {
                             if (i + u < cnt) {
-                                uint32_t e = g.l1[(uint32_t)(hi >> sh1)];
+                                uint32_t e = g.l1[b3 >> sh1];
                                 if (e == L1_ESC) { // a code longer than the first level: canonical rank search
-                                    uint32_t v = (uint32_t)(hi >> sh2), w = 1;
+                                    uint32_t v = b3 >> sh2, w = 1;
                                     for (uint32_t x = 2; x <= tl; x++) w += v >= g.rs[x];
                                     e = g.syms[g.ss[w] + ((v - g.rs[w]) >> (w - 1))] | ((tl + 1 - w) << 8);
                                 }
                                 const uint32_t nb = e >> 8; // 1..11
-                                hi = (hi << nb) | (lo >> (64 - nb));
-                                lo <<= nb;
+                                shift_bits(nb);
                                 avail -= (int)nb;
                                 used_bits += nb;
                                 const uint32_t k = (i + u) & 63;
