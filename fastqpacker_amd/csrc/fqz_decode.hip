@@ -757,7 +757,6 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                 if (!sn || !sp[sn - 1]) fail = 1;
                 else {
                     const int hb = highbit32_d(sp[sn - 1]);
-                    const uint32_t total_bits = (sn - 1) * 8 + (uint32_t)hb;
                     uint32_t b3 = 0, b2 = 0, b1 = 0, b0 = 0; // the bit buffer as four words (b3 on top): a shift is three v_alignbit + one shift
                     int avail = 0;            // valid bits in b3:b2:b1:b0
                     int byte_pos = (int)sn;   // bytes [0, byte_pos) not fetched yet
@@ -795,7 +794,7 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                     const uint32_t sh1 = 32 - l1b, sh2 = 32 - tl;
                     const bool aligned = (((uintptr_t)dst) & 15) == 0;
                     uint8_t *ob = (uint8_t *)obuf + (lane << 2);
-                    uint32_t used_bits = 0;
+                    int neg = 0; // sign bit set once the buffer ran dry (a corrupt stream)
                     for (uint32_t i = 0; i < cnt; i += 4) {
                         // top-up loads for this iteration (0, 1 or 2 dwords)
                         uint32_t w0 = 0, w1 = 0;
@@ -819,12 +818,12 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                                 const uint32_t nb = e >> 8; // 1..11
                                 shift_bits(nb);
                                 avail -= (int)nb;
-                                used_bits += nb;
                                 const uint32_t k = (i + u) & 63;
                                 ob[((k >> 2) << 8) + (k & 3)] = (uint8_t)e; // transposed staging: dword k/4 of this lane
                             }
                         }
-                        if (avail < 0) avail = 0; // corrupt stream: caught by the bit count below
+                        neg |= avail;
+                        if (avail < 0) avail = 0; // corrupt stream: caught below
                         merge(w0, n0);
                         merge(w1, n1);
                         const uint32_t done = i + 4 < cnt ? i + 4 : cnt;
@@ -841,7 +840,9 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                             }
                         }
                     }
-                    if (used_bits != total_bits) fail = 1;
+                    // every bit of the stream must have gone into a symbol: all bytes fetched (the refills see to that as the
+                    // buffer drains) and the buffer empty (8 * sn - pad payload bits were merged in all)
+                    if (neg < 0 || byte_pos != 0 || avail != 0) fail = 1;
                 }
             }
         }
