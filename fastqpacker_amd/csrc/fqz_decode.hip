@@ -806,21 +806,27 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                             if (avail <= 96) fetch(w0, n0);
                             if (avail <= 64) fetch(w1, n1);
                         }
-#pragma unroll
-                        for (uint32_t u = 0; u < 4; u++) {
-                            if (i + u < cnt) {
-                                uint32_t e = g.l1[b3 >> sh1];
-                                if (e == L1_ESC) { // a code longer than the first level: canonical rank search
-                                    uint32_t v = b3 >> sh2, w = 1;
-                                    for (uint32_t x = 2; x <= tl; x++) w += v >= g.rs[x];
-                                    e = g.syms[g.ss[w] + ((v - g.rs[w]) >> (w - 1))] | ((tl + 1 - w) << 8);
-                                }
-                                const uint32_t nb = e >> 8; // 1..11
-                                shift_bits(nb);
-                                avail -= (int)nb;
-                                const uint32_t k = (i + u) & 63;
-                                ob[((k >> 2) << 8) + (k & 3)] = (uint8_t)e; // transposed staging: dword k/4 of this lane
+                        auto symbol = [&](uint32_t u) {
+                            uint32_t e = g.l1[b3 >> sh1];
+                            if (e == L1_ESC) { // a code longer than the first level: canonical rank search
+                                uint32_t v = b3 >> sh2, w = 1;
+                                for (uint32_t x = 2; x <= tl; x++) w += v >= g.rs[x];
+                                e = g.syms[g.ss[w] + ((v - g.rs[w]) >> (w - 1))] | ((tl + 1 - w) << 8);
                             }
+                            const uint32_t nb = e >> 8; // 1..11
+                            shift_bits(nb);
+                            avail -= (int)nb;
+                            const uint32_t k = (i + u) & 63;
+                            ob[((k >> 2) << 8) + (k & 3)] = (uint8_t)e; // transposed staging: dword k/4 of this lane
+                        };
+                        // all four symbols exist for every lane except in a stream's last iteration: no per-symbol predicate then
+                        if (__builtin_amdgcn_ballot_w64(i + 4 > cnt) == 0) {
+#pragma unroll
+                            for (uint32_t u = 0; u < 4; u++) symbol(u);
+                        } else {
+#pragma unroll
+                            for (uint32_t u = 0; u < 4; u++)
+                                if (i + u < cnt) symbol(u);
                         }
                         neg |= avail;
                         if (avail < 0) avail = 0; // corrupt stream: caught below
