@@ -937,7 +937,9 @@ __global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *
 //   k_dec_walk2  per (block, stream): chain the true entry offsets through F (one hop per tile)
 //   k_dec_walk3  per tile: one lane walks from the true entry and writes the record offsets
 // ---------------------------------------------------------------------------
-#define WALK_TILE 16384u
+#ifndef WALK_TILE
+#define WALK_TILE 8192u // A/B on one box, walk1 + walk2 + walk3: 0.53 ms at 8 KiB, 0.63 at 16 KiB, 1.15 at 32 KiB
+#endif
 #define WALK_ENTRIES 256u
 #define WALK_END 0xFFFFFFFFu
 struct WalkF { uint32_t exit, cnt; };      // exit: offset into the next tile, or WALK_END when the stream ended
@@ -1032,6 +1034,9 @@ __global__ __launch_bounds__(256) void k_dec_walk1(const uint8_t *arena, const D
     F[(size_t)tidx * WALK_ENTRIES + threadIdx.x] = f;
 }
 
+#ifndef W2_BATCH
+#define W2_BATCH 8u // (32 measured slower: 0.106 vs 0.077 ms)
+#endif
 __global__ __launch_bounds__(64) void k_dec_walk2(const uint8_t *arena, DecInfo *info, const DecBlock *blocks, const WalkF *F, WalkEntry *entries)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[WALK_TILE + 16];
@@ -1044,43 +1049,63 @@ __global__ __launch_bounds__(64) void k_dec_walk2(const uint8_t *arena, DecInfo 
     const uint32_t unit = s == S_NPOS ? 2 : 1, len = b->raw_len[s], nrec = b->nrec, cand = b->walk_cand[which];
     const uint32_t nt = (len + WALK_TILE - 1) / WALK_TILE, tb = b->tile_base[which];
     const uint8_t *p = arena + b->a_off[s];
-    // every lane carries the same chain state (the loop is uniform); lane 0 writes
+    // every lane carries the same chain state (the loop is uniform); lane 0 writes.  The chain hops from tile to tile
+    // through F[tile][entry offset]: fetched one hop at a time that is a dependent global load per tile, so the first 64
+    // entries of W2_BATCH tiles are loaded at once (lane l holds entry l: one memory round trip per batch) and a hop is a
+    // cross-lane read.
     uint32_t e = 0, base = 0;
     bool ended = false;
-    for (uint32_t k = 0; k < nt; k++) {
-        WalkEntry we;
-        we.e = (ended || base >= nrec) ? WALK_END : e;
-        we.base = base;
-        if (threadIdx.x == 0) entries[tb + k] = we;
-        if (we.e == WALK_END) continue;
-        if (e >= WALK_TILE) { e -= WALK_TILE; continue; } // a long record covers this whole tile
-        WalkF f;
-        if (e < cand) f = F[(size_t)(tb + k) * WALK_ENTRIES + e];
-        else { // entry beyond the precomputed range (a record longer than cand - 2 bytes precedes): stage the tile and walk it here
-            const uint32_t t0 = k * WALK_TILE;
-            __syncthreads();
-            walk_load_tile(tile, p, t0, len, threadIdx.x, 64);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t pos = e, cnt = 0;
-                for (;;) {
-                    if (t0 + pos + 2 > len) { f.exit = WALK_END; break; }
-                    if (pos >= WALK_TILE) { f.exit = pos - WALK_TILE; break; }
-                    uint16_t k16;
-                    __builtin_memcpy(&k16, tile + pos, 2);
-                    cnt++;
-                    unsigned long long nxt = (unsigned long long)pos + 2 + (unsigned long long)k16 * unit;
-                    if (t0 + nxt > len) { f.exit = WALK_END; break; }
-                    pos = (uint32_t)nxt;
-                }
-                f.cnt = cnt;
-                s_f = f;
-            }
-            __syncthreads();
-            f = s_f;
+    for (uint32_t k0 = 0; k0 < nt; k0 += W2_BATCH) {
+        WalkF row[W2_BATCH];
+#pragma unroll
+        for (uint32_t j = 0; j < W2_BATCH; j++) {
+            row[j].exit = WALK_END;
+            row[j].cnt = 0;
+            if (k0 + j < nt) row[j] = F[(size_t)(tb + k0 + j) * WALK_ENTRIES + threadIdx.x]; // (walk_cand >= 64 = the lanes of this wave)
         }
-        base += f.cnt;
-        if (f.exit == WALK_END) ended = true; else e = f.exit;
+#pragma unroll
+        for (uint32_t j = 0; j < W2_BATCH; j++) {
+            const uint32_t k = k0 + j;
+            if (k >= nt) break;
+            WalkEntry we;
+            we.e = (ended || base >= nrec) ? WALK_END : e;
+            we.base = base;
+            if (threadIdx.x == 0) entries[tb + k] = we;
+            if (we.e == WALK_END) continue;
+            if (e >= WALK_TILE) { e -= WALK_TILE; continue; } // a long record covers this whole tile
+            WalkF f;
+            if (e < 64) { // e is wave-uniform: a v_readlane with the lane in an SGPR, no LDS round trip in the chain
+                const int el = __builtin_amdgcn_readfirstlane((int)e);
+                f.exit = (uint32_t)__builtin_amdgcn_readlane((int)row[j].exit, el);
+                f.cnt = (uint32_t)__builtin_amdgcn_readlane((int)row[j].cnt, el);
+            }
+            else if (e < cand) f = F[(size_t)(tb + k) * WALK_ENTRIES + e];
+            else { // entry beyond the precomputed range (a record longer than cand - 2 bytes precedes): stage the tile and walk it here
+                const uint32_t t0 = k * WALK_TILE;
+                __syncthreads();
+                walk_load_tile(tile, p, t0, len, threadIdx.x, 64);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    uint32_t pos = e, cnt = 0;
+                    for (;;) {
+                        if (t0 + pos + 2 > len) { f.exit = WALK_END; break; }
+                        if (pos >= WALK_TILE) { f.exit = pos - WALK_TILE; break; }
+                        uint16_t k16;
+                        __builtin_memcpy(&k16, tile + pos, 2);
+                        cnt++;
+                        unsigned long long nxt = (unsigned long long)pos + 2 + (unsigned long long)k16 * unit;
+                        if (t0 + nxt > len) { f.exit = WALK_END; break; }
+                        pos = (uint32_t)nxt;
+                    }
+                    f.cnt = cnt;
+                    s_f = f;
+                }
+                __syncthreads();
+                f = s_f;
+            }
+            base += f.cnt;
+            if (f.exit == WALK_END) ended = true; else e = f.exit;
+        }
     }
     if (base < nrec && threadIdx.x == 0) dec_fail(info, walk_err((int)which)); // the stream ran out before NumRecords records
 }
