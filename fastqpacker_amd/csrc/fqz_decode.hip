@@ -1057,6 +1057,9 @@ __global__ __launch_bounds__(64) void k_dec_walk2(const uint8_t *arena, DecInfo 
     bool ended = false;
     for (uint32_t k0 = 0; k0 < nt; k0 += W2_BATCH) {
         WalkF row[W2_BATCH];
+        WalkEntry mine;
+        mine.e = WALK_END;
+        mine.base = 0;
 #pragma unroll
         for (uint32_t j = 0; j < W2_BATCH; j++) {
             row[j].exit = WALK_END;
@@ -1070,7 +1073,7 @@ __global__ __launch_bounds__(64) void k_dec_walk2(const uint8_t *arena, DecInfo 
             WalkEntry we;
             we.e = (ended || base >= nrec) ? WALK_END : e;
             we.base = base;
-            if (threadIdx.x == 0) entries[tb + k] = we;
+            if (threadIdx.x == j) mine = we; // stored after the batch: a store per hop would be waited for (vmcnt) by the next hop
             if (we.e == WALK_END) continue;
             if (e >= WALK_TILE) { e -= WALK_TILE; continue; } // a long record covers this whole tile
             WalkF f;
@@ -1106,6 +1109,7 @@ __global__ __launch_bounds__(64) void k_dec_walk2(const uint8_t *arena, DecInfo 
             base += f.cnt;
             if (f.exit == WALK_END) ended = true; else e = f.exit;
         }
+        if (threadIdx.x < W2_BATCH && k0 + threadIdx.x < nt) entries[tb + k0 + threadIdx.x] = mine; // lane j: tile k0 + j
     }
     if (base < nrec && threadIdx.x == 0) dec_fail(info, walk_err((int)which)); // the stream ran out before NumRecords records
 }
