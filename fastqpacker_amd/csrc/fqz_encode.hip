@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
         // ---- bases and qualities share the piece map (both lines of a record have L bytes): one pass, both loads in flight.
         // bases: 16 bases -> 4 packed bytes (sequence.go:139-184); N counts go to E[nPos] (compress.go:477-488)
         // quality: q'[0] = q[0]-off, q'[j] = q[j]-q[j-1], restarting per record (quality.go:53-103)
-        struct PieceJob { bool on; uint32_t i, k, have, dst, dstq, srcq, x[4], y[4]; };
+        struct PieceJob { bool on; uint32_t i, k, have, dst, dstq, srcq, x[4], y[4], out, nn, beyond; };
         auto fetch = [&](uint32_t p, PieceJob &J) { // every lane of the wave calls this
             J.on = p < Tq;
             piece_locate(pm_iq, iq, pq, J.on ? p : 0, &J.i, &J.k);
@@ -698,13 +698,14 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
                 load_piece(text, J.srcq + 16 * J.k, n_text, J.y);
             }
         };
-        auto finish = [&](PieceJob &J) {
+        // registers only (plus lane 0's one byte): x -> packed bases in `out`, y -> delta-coded qualities in y
+        auto compute = [&](PieceJob &J) {
             // the byte before a quality piece is the last byte of the previous lane's piece (same read, k - 1); only lane 0
             // has to fetch it from the text
             const uint32_t left = (uint32_t)__shfl_up((int)(J.y[3] >> 24), 1, WAVE);
+            J.out = J.nn = J.beyond = 0;
             if (J.on) {
                 const uint32_t have = J.have, k = J.k;
-                uint32_t out = 0, nn = 0, beyond = 0;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     uint32_t v = J.x[q], in_read = 0x80808080u;
@@ -715,15 +716,25 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
                     }
                     const uint32_t vmask = acgt_mask(v);
                     const uint32_t invalid = ~vmask & in_read;
-                    out |= pack4(v, vmask) << (8 * q);
+                    J.out |= pack4(v, vmask) << (8 * q);
                     if (invalid) {
                         const uint32_t b0 = 16 * k + 4 * q;
-                        if (b0 + 3 < FQZ_MAX_SEQUENCE_LENGTH) nn += __popc(invalid);
+                        if (b0 + 3 < FQZ_MAX_SEQUENCE_LENGTH) J.nn += __popc(invalid);
                         else
                             for (uint32_t z = 0; z < 4; z++)
-                                if (invalid & (0x80u << (8 * z))) { if (b0 + z < FQZ_MAX_SEQUENCE_LENGTH) nn++; else beyond = 1; }
+                                if (invalid & (0x80u << (8 * z))) { if (b0 + z < FQZ_MAX_SEQUENCE_LENGTH) J.nn++; else J.beyond = 1; }
                     }
                 }
+                uint32_t prev = k ? (lane ? left : text[J.srcq + 16 * k - 1]) : qoff;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const uint32_t yq = J.y[q]; J.y[q] = sub_bytes(yq, (yq << 8) | (prev & 0xFF)); prev = yq >> 24; }
+            }
+        };
+        // stores and atomics, after every load of the trip has been consumed: stores count in vmcnt like loads (gfx9), and a
+        // wait for the next round's loads behind them would wait for their acknowledgements too
+        auto commit = [&](PieceJob &J) {
+            if (J.on) {
+                const uint32_t have = J.have, k = J.k, out = J.out;
                 const uint32_t nb = (have + 3) >> 2;
                 uint8_t *o = arena + J.dst + 4 * k;
                 if (nb == 4) store_u32_unaligned(o, out);
@@ -731,13 +742,9 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
                     if (nb & 2) { uint16_t v = (uint16_t)out; __builtin_memcpy(o, &v, 2); }
                     if (nb & 1) o[nb & 2] = (uint8_t)(out >> (8 * (nb & 2)));
                 }
-                if (beyond) report_error(info, g * 64 + J.i, 4, FQZ_E_LONG_N);
-                if (nn) atomicAdd(&Enpos[g * 64 + J.i], 2 * nn);
-                uint32_t w[4];
-                uint32_t prev = k ? (lane ? left : text[J.srcq + 16 * k - 1]) : qoff;
-#pragma unroll
-                for (int q = 0; q < 4; q++) { w[q] = sub_bytes(J.y[q], (J.y[q] << 8) | (prev & 0xFF)); prev = J.y[q] >> 24; }
-                store_piece(arena + J.dstq + 16 * k, w, have);
+                if (J.beyond) report_error(info, g * 64 + J.i, 4, FQZ_E_LONG_N);
+                if (J.nn) atomicAdd(&Enpos[g * 64 + J.i], 2 * J.nn);
+                store_piece(arena + J.dstq + 16 * k, J.y, have);
             }
         };
         // several rounds of 64 pieces per trip: 2 x SPLIT_ROUNDS loads per lane in flight before the first one is used
@@ -748,7 +755,10 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
                 if (base + u * WAVE < Tq) fetch(base + u * WAVE + lane, J[u]);
 #pragma unroll
             for (uint32_t u = 0; u < SPLIT_ROUNDS; u++)
-                if (base + u * WAVE < Tq) finish(J[u]);
+                if (base + u * WAVE < Tq) compute(J[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < SPLIT_ROUNDS; u++)
+                if (base + u * WAVE < Tq) commit(J[u]);
         }
         // ---- header and plus payloads (without '@' / '+'), after their u16 length
         for (uint32_t base = 0; base < Th; base += WAVE) {
