@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
         // bases: 4 packed bytes -> 16 ASCII bases (unpackLookupUint32, sequence.go:36-42)
         // quality: inclusive prefix sum mod 256 (DeltaDecode, quality.go:105-118) + offset (DenormalizeQuality)
         {
-            struct PieceJob { bool on; uint32_t k, nbytes, dseq, dq, vs; uint4 vq; };
+            struct PieceJob { bool on; uint32_t k, nbytes, dseq, dq, vs, xs[4], xq[4]; uint4 vq; };
             uint32_t carry = 0; // sum of the pieces of the record in progress that earlier rounds handled
             auto fetch = [&](uint32_t p, PieceJob &J) { // every lane of the wave calls this
                 J.on = p < Tq;
@@ -1289,18 +1289,15 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
                     J.vq = load_u128_unaligned(arena + sq + 16 * J.k);
                 }
             };
-            auto finish = [&](PieceJob &J) {
+            // registers only: vs -> 16 ASCII bases in xs, vq -> the 16 quality bytes in xq
+            auto compute = [&](PieceJob &J) {
                 const uint32_t k = J.k, nbytes = J.on ? J.nbytes : 0;
-                if (J.on) {
-                    uint32_t x[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t b8 = (J.vs >> (8 * q)) & 0xFF;
-                        const uint32_t nib = (b8 | (b8 << 12)) & 0x000F000Fu;        // bases 0,1 | bases 2,3
-                        const uint32_t codes = (nib | (nib << 6)) & 0x03030303u;     // byte j = 2-bit code of base j
-                        x[q] = __builtin_amdgcn_perm(0u, 0x54474341u, codes);                         // "ACGT"[code]
-                    }
-                    store_piece(out + J.dseq, x, nbytes);
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t b8 = (J.vs >> (8 * q)) & 0xFF;
+                    const uint32_t nib = (b8 | (b8 << 12)) & 0x000F000Fu;        // bases 0,1 | bases 2,3
+                    const uint32_t codes = (nib | (nib << 6)) & 0x03030303u;     // byte j = 2-bit code of base j
+                    J.xs[q] = __builtin_amdgcn_perm(0u, 0x54474341u, codes);                      // "ACGT"[code]
                 }
                 uint32_t x[4] = {0, 0, 0, 0};
                 if (J.on) {
@@ -1323,21 +1320,28 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
                 const uint32_t incl = wave_incl_scan(tot), excl = incl - tot;
                 const uint32_t head_excl = DSH(excl, lane >= k ? lane - k : 0);
                 const uint32_t before = (lane >= k ? excl - head_excl : carry + excl) & 0xFF;
-                if (J.on) {
-                    const uint32_t add = ((qoff + before) & 0xFF) * 0x01010101u;
+                const uint32_t add = ((qoff + before) & 0xFF) * 0x01010101u;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) x[q] = add_bytes(x[q], add);
-                    store_piece(out + J.dq, x, nbytes);
-                }
+                for (int q = 0; q < 4; q++) J.xq[q] = add_bytes(x[q], add);
                 carry = DRL(before + tot, 63) & 0xFF; // only read by lanes whose record started before the next round
+            };
+            // stores last, when every load of the trip has been consumed (stores count in vmcnt like loads: a wait for the
+            // second round's loads behind the first round's stores would wait for those too)
+            auto commit = [&](PieceJob &J) {
+                if (J.on) {
+                    store_piece(out + J.dseq, J.xs, J.nbytes);
+                    store_piece(out + J.dq, J.xq, J.nbytes);
+                }
             };
             for (uint32_t base = 0; base < Tq; base += 2 * WAVE) {
                 PieceJob A, B;
                 fetch(base + lane, A);
                 const bool two = base + WAVE < Tq;
                 if (two) fetch(base + WAVE + lane, B);
-                finish(A);
-                if (two) finish(B);
+                compute(A);
+                if (two) compute(B);
+                commit(A);
+                if (two) commit(B);
             }
         }
         // ---- the fixed bytes of the record: '@', the three '\n' after header / sequence / plus, '+', the final '\n'.
