@@ -959,6 +959,9 @@ __global__ __launch_bounds__(1024) void k_dec_walk0(const uint8_t *arena, DecInf
     const uint32_t len = b->raw_len[s], nrec = b->nrec, t = threadIdx.x;
     uint32_t *out = offs + (size_t)which * ostride + b->rec_base;
     uint32_t mode = 0; // 0 = walk, 1 = done here
+    // every record owns a 2-byte prefix in these streams (compress.go:977-980, 1055-1060): a stream too short for nrec prefixes
+    // is truncated whatever it holds (and would otherwise leave the offsets of its records unwritten)
+    if ((unsigned long long)len < 2ull * nrec && !(s == S_PLUS && len == 0)) { if (t == 0) dec_fail(info, walk_err((int)which)); return; }
     if (s == S_PLUS && len == 0) { // v1 container or all-bare '+': appendPlusLine's fast path (compress.go:995-999)
         for (uint32_t r = t; r < nrec; r += 1024) out[r] = 0;
         mode = 1;
@@ -1156,40 +1159,73 @@ __device__ __forceinline__ uint32_t find_block(const DecBlock *blocks, uint32_t 
     return lo;
 }
 
+// btot[block][3]: 64-bit sums of the three columns per block: the 32-bit columns (and their scans) may wrap for a crafted
+// block, the totals that the truncation checks compare may not
 __global__ __launch_bounds__(256) void k_dec_sizes(const uint8_t *arena, DecInfo *info, const DecBlock *blocks, const uint32_t *offs,
-                                                   uint32_t ostride, uint32_t *cols, uint32_t cstride)
+                                                   uint32_t ostride, uint32_t *cols, uint32_t cstride, unsigned long long *btot)
 {
     uint32_t n_rec = info->n_rec, nb = info->n_blocks;
     if (info->status) return;
-    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
-        const DecBlock *b = &blocks[find_block(blocks, nb, r)];
-        uint32_t lr = r - b->rec_base;
-        if (4ull * (lr + 1) > b->raw_len[S_LEN]) { dec_fail(info, FQZ_E_TRUNC_LEN); return; } // readSeqLength compress.go:1046
-        uint32_t L = *(const uint32_t *)(arena + b->a_off[S_LEN] + 4 * lr);
-        if (L > 0x7FFFFFFFu) { dec_fail(info, FQZ_E_TRUNC_SEQ); return; }
-        uint32_t H = rd16(arena + b->a_off[S_HDR] + offs[r]);
-        uint32_t P = b->raw_len[S_PLUS] ? rd16(arena + b->a_off[S_PLUS] + offs[ostride + r]) : 0;
-        cols[r] = (L + 3) >> 2;
-        cols[cstride + r] = L;
-        cols[2 * (size_t)cstride + r] = H + P + 2 * L + 6;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t r0 = blockIdx.x * 256; r0 < n_rec; r0 += gridDim.x * 256) {
+        const uint32_t r = r0 + threadIdx.x;
+        unsigned long long v0 = 0, v1 = 0, v2 = 0;
+        uint32_t bi = 0xFFFFFFFFu;
+        if (r < n_rec) {
+            bi = find_block(blocks, nb, r);
+            const DecBlock *b = &blocks[bi];
+            uint32_t lr = r - b->rec_base;
+            if (4ull * (lr + 1) > b->raw_len[S_LEN]) { dec_fail(info, FQZ_E_TRUNC_LEN); bi = 0xFFFFFFFFu; } // readSeqLength compress.go:1046
+            else {
+                uint32_t L = *(const uint32_t *)(arena + b->a_off[S_LEN] + 4 * lr);
+                // appendSequence / appendQuality (compress.go:1017-1041) check every record against what is left of the stream
+                if (((unsigned long long)L + 3) / 4 > b->raw_len[S_SEQ]) { dec_fail(info, FQZ_E_TRUNC_SEQ); L = 0; }
+                else if (L > b->raw_len[S_QUAL]) { dec_fail(info, FQZ_E_TRUNC_QUAL); L = 0; }
+                uint32_t H = rd16(arena + b->a_off[S_HDR] + offs[r]);
+                uint32_t P = b->raw_len[S_PLUS] ? rd16(arena + b->a_off[S_PLUS] + offs[ostride + r]) : 0;
+                v0 = (L + 3) >> 2; v1 = L; v2 = (unsigned long long)H + P + 2ull * L + 6;
+                cols[r] = (uint32_t)v0;
+                cols[cstride + r] = (uint32_t)v1;
+                cols[2 * (size_t)cstride + r] = (uint32_t)v2;
+            }
+        }
+        // block totals: one atomic per wave when the wave's records share a block (almost always)
+        const uint32_t b_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)bi);
+        if (__ballot(bi != b_first) == 0) {
+            if (b_first != 0xFFFFFFFFu) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) { v0 += __shfl_xor(v0, d, WAVE); v1 += __shfl_xor(v1, d, WAVE); v2 += __shfl_xor(v2, d, WAVE); }
+                if (lane == 0) { atomicAdd(&btot[3ull * b_first], v0); atomicAdd(&btot[3ull * b_first + 1], v1); atomicAdd(&btot[3ull * b_first + 2], v2); }
+            }
+        } else if (bi != 0xFFFFFFFFu) {
+            atomicAdd(&btot[3ull * bi], v0); atomicAdd(&btot[3ull * bi + 1], v1); atomicAdd(&btot[3ull * bi + 2], v2);
+        }
     }
 }
 
 // block totals vs stream lengths: the truncation errors of appendSequence / appendQuality
-__global__ void k_dec_check(DecInfo *info, const DecBlock *blocks, const uint32_t *cols, uint32_t cstride, size_t out_cap)
+// one workgroup: the 64-bit totals of every block against its stream lengths, their sum against the output capacity
+__global__ __launch_bounds__(256) void k_dec_check(DecInfo *info, const DecBlock *blocks, const unsigned long long *btot, size_t out_cap)
 {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long s_sum[256];
     if (info->status) return;
-    if (b == 0) {
-        unsigned long long tot = cols[2 * (size_t)cstride + info->n_rec];
-        info->out_len = tot;
-        if (tot > out_cap) dec_fail(info, FQZ_E_DST_SMALL);
+    const uint32_t nb = info->n_blocks;
+    unsigned long long mine = 0;
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+        const DecBlock *k = &blocks[b];
+        if (btot[3ull * b] > k->raw_len[S_SEQ]) dec_fail(info, FQZ_E_TRUNC_SEQ);
+        if (btot[3ull * b + 1] > k->raw_len[S_QUAL]) dec_fail(info, FQZ_E_TRUNC_QUAL);
+        mine += btot[3ull * b + 2];
     }
-    if (b >= info->n_blocks) return;
-    const DecBlock *k = &blocks[b];
-    uint32_t r0 = k->rec_base, r1 = r0 + k->nrec;
-    if (cols[r1] - cols[r0] > k->raw_len[S_SEQ]) dec_fail(info, FQZ_E_TRUNC_SEQ);
-    if (cols[cstride + r1] - cols[cstride + r0] > k->raw_len[S_QUAL]) dec_fail(info, FQZ_E_TRUNC_QUAL);
+    s_sum[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 256; i++) tot += s_sum[i];
+        info->out_len = tot;
+        if (tot > 0xFFFFFFF0ull) dec_fail(info, FQZ_E_TOO_LARGE); // output offsets are 32 bits
+        else if (tot > out_cap) dec_fail(info, FQZ_E_DST_SMALL);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1509,6 +1545,15 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         }
         out_bound += (unsigned long long)hb[b].raw_len[S_HDR] + hb[b].raw_len[S_PLUS] + 2ull * hb[b].raw_len[S_QUAL] + 4ull * hb[b].nrec;
     }
+    // NumRecords comes from the (untrusted) block header: tie it to the decoded stream sizes before anything is sized from it.
+    // Order as blockReader.writeRecord meets them (compress.go:944-975): length, N positions, header.
+    for (uint32_t b = 0; b < nb; b++) {
+        const unsigned long long nr = hb[b].nrec;
+        if (4ull * nr > hb[b].raw_len[S_LEN]) return FQZ_E_TRUNC_LEN;
+        if (2ull * nr > hb[b].raw_len[S_NPOS]) return FQZ_E_TRUNC_NPOS;
+        if (2ull * nr > hb[b].raw_len[S_HDR]) return FQZ_E_TRUNC_HEADER;
+        if (hb[b].raw_len[S_PLUS] && 2ull * nr > hb[b].raw_len[S_PLUS]) return FQZ_E_TRUNC_PLUS;
+    }
     if (arena > 0xFFFFFFF0ull || chunks > 0x7FFFFFFFull || out_bound > 0xFFFFFFF0ull || tiles > 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
     const uint32_t n_tiles = (uint32_t)tiles;
     if (!d_out) { // host-buffer entry points: decode into the context's staging buffer
@@ -1524,13 +1569,15 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     if ((rc = d.chunks.ensure(sizeof(DecChunk) * ((size_t)n_chunks + 1)))) return rc;
     if ((rc = d.rec.ensure(4ull * (3ull * ostride + 3ull * cstride) + 64))) return rc;
     uint32_t pmax = n_rec / DSCAN_TILE + 2;
-    if ((rc = d.partials.ensure(4ull * 3 * pmax))) return rc;
+    if ((rc = d.partials.ensure(4ull * 3 * pmax + 24ull * ((size_t)nb + 1)))) return rc;
     if ((rc = d.tables.ensure(((size_t)n_tiles + 1) * (WALK_ENTRIES * sizeof(WalkF) + sizeof(WalkEntry))))) return rc;
     WalkF *walkF = d.tables.as<WalkF>();
     WalkEntry *walkE = (WalkEntry *)(walkF + ((size_t)n_tiles + 1) * WALK_ENTRIES);
     DecChunk *dch = d.chunks.as<DecChunk>();
     uint8_t *darena = d.streams.as<uint8_t>();
     uint32_t *offs = d.rec.as<uint32_t>(), *cols = offs + 3ull * ostride, *partials = d.partials.as<uint32_t>();
+    unsigned long long *btot = (unsigned long long *)(partials + ((3ull * pmax + 1) & ~1ull)); // 64-bit column totals per block
+    HIP_TRY(hipMemsetAsync(btot, 0, 24ull * nb, st));
     HIP_TRY(hipMemcpyAsync(blocks, hb, sizeof(DecBlock) * (size_t)nb, hipMemcpyHostToDevice, st));
     hi->n_chunks = n_chunks;
     HIP_TRY(hipMemcpyAsync(&info->n_chunks, &hi->n_chunks, 4, hipMemcpyHostToDevice, st));
@@ -1568,7 +1615,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     if (n_rec) {
         uint32_t g = (n_rec + 255) / 256;
         if (g > 4096) g = 4096;
-        PROF(ctx, st, "k_dec_sizes", hipLaunchKernelGGL(k_dec_sizes, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride));
+        PROF(ctx, st, "k_dec_sizes", hipLaunchKernelGGL(k_dec_sizes, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride, btot));
     }
     {
         uint32_t nwg = (n_rec + DSCAN_TILE - 1) / DSCAN_TILE;
@@ -1577,7 +1624,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         hipLaunchKernelGGL(k_dscan_top, dim3(3), dim3(256), 0, st, cols, &info->n_rec, cstride, partials, pmax);
         hipLaunchKernelGGL(k_dscan_apply, dim3(nwg, 3), dim3(256), 0, st, cols, &info->n_rec, cstride, partials, pmax);
     }
-    PROF(ctx, st, "k_dec_check", hipLaunchKernelGGL(k_dec_check, dim3((nb + 63) / 64), dim3(64), 0, st, info, blocks, cols, cstride, out_cap));
+    PROF(ctx, st, "k_dec_check", hipLaunchKernelGGL(k_dec_check, dim3(1), dim3(256), 0, st, info, blocks, btot, out_cap));
     if (n_rec) {
         uint32_t g = ((n_rec + 63) / 64 + 3) / 4;
         if (g > 8192) g = 8192;

@@ -257,3 +257,50 @@ def test_stock_style_container_decodes(fq):
     assert fq.compress.decode_block(block, 2, 0) == text
     # and whole-file: header + block through Decompress
     assert fq.compress.Decompress(fqz[:10] + block) == text
+
+
+def _v2_block(nrec, streams, orig=0):
+    """A v2 block whose six payloads (stream order seq, qual, headers, plus, nPos, lengths) are oracle frames."""
+    import struct
+    pays = [O.entropy_encode(s) if len(s) else b"" for s in streams]
+    return struct.pack("<9I", nrec, *[len(p) for p in pays], orig, orig) + b"".join(pays)
+
+
+def test_crafted_blocks_whose_sizes_wrap_32_bits_are_refused(fq):
+    """per-record sizes and their sums must not wrap: 16 records of L = 2^30 make every 32-bit total 0."""
+    import struct
+    nrec = 16
+    lengths = struct.pack("<I", 0x40000000) * nrec
+    block = _v2_block(nrec, [b"", b"", b"\x00\x00" * nrec, b"", b"\x00\x00" * nrec, lengths])
+    with pytest.raises(fq.FqzError, match="truncated"):
+        fq.compress.decode_block(block, 2, 0)
+    # a single record with the largest length the old bound let through
+    block = _v2_block(1, [b"", b"", b"\x00\x00", b"", b"\x00\x00", struct.pack("<I", 0x7FFFFFFF)])
+    with pytest.raises(fq.FqzError, match="truncated"):
+        fq.compress.decode_block(block, 2, 0)
+    # lengths that fit the streams individually but not in sum (64-bit block totals)
+    seq, qual = b"\x00" * 3, b"\x05" * 10
+    block = _v2_block(3, [seq, qual, b"\x00\x00" * 3, b"", b"\x00\x00" * 3, struct.pack("<3I", 10, 10, 10)])
+    with pytest.raises(fq.FqzError, match="truncated (sequence|quality) data"):
+        fq.compress.decode_block(block, 2, 0)
+
+
+def test_streams_too_short_for_their_records_are_refused(fq):
+    """ADVICE r1 (medium / low): NumRecords is tied to the stream sizes before anything is sized or walked from it."""
+    import struct
+    one = struct.pack("<I", 4)
+    # records but an empty header stream (compress.go:977-980)
+    with pytest.raises(fq.FqzError, match="truncated header data"):
+        fq.compress.decode_block(_v2_block(1, [b"\x00", b"IIII", b"", b"", b"\x00\x00", one]), 2, 0)
+    # ... an empty N-position stream (compress.go:1055-1060)
+    with pytest.raises(fq.FqzError, match="truncated N position data"):
+        fq.compress.decode_block(_v2_block(1, [b"\x00", b"IIII", b"\x01\x00A", b"", b"", one]), 2, 0)
+    # a block header that claims half a billion records over a 4-byte lengths stream: refused before any large allocation
+    with pytest.raises(fq.FqzError, match="truncated length data"):
+        fq.compress.decode_block(_v2_block(500_000_000, [b"\x00", b"IIII", b"\x01\x00A", b"", b"\x00\x00", one]), 2, 0)
+    # a plus stream that is present but shorter than its prefixes
+    with pytest.raises(fq.FqzError, match="truncated plus-line payload data"):
+        fq.compress.decode_block(_v2_block(2, [b"\x00\x00", b"IIIIIIII", b"\x01\x00A\x01\x00B", b"\x00\x00", b"\x00\x00" * 2, one * 2]), 2, 0)
+    # the well-formed twin decodes
+    ok = _v2_block(1, [b"\x00", b"\x28\x00\x00\x00", b"\x01\x00A", b"", b"\x00\x00", one])
+    assert fq.compress.decode_block(ok, 2, 0) == b"@A\nAAAA\n+\nIIII\n"
