@@ -94,7 +94,6 @@ SIGNATURES = {
     "fqz_decode_batch_finish": (C.c_int, [_vp, C.POINTER(BatchResult)]),
     "fqz_debug_get_streams": (C.c_int, [_vp, C.c_uint32, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "fqz_debug_get_stamps": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
-    "fqz_debug_get_fs_stamps": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]),
     "fqz_pack_bases": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _vp, _vp, C.POINTER(C.c_size_t)]),
     "fqz_unpack_bases": (C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t, C.c_size_t, _vp]),
     "fqz_detect_encoding": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_int)]),

@@ -95,9 +95,8 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     EncState &e = c->enc;
-    DevBuf *eb[] = {&e.info, &e.Enpos, &e.rec_seq, &e.rec_L, &e.bstart, &e.plans, &e.slots, &e.csize, &e.stamps, &e.fs_stamps, &e.zstate, &e.scan_state, &e.gmap};
+    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.stamps, &e.lf, &e.zstate, &e.scan_state, &e.gmap};
     for (DevBuf *b : eb) b->release();
-    for (DevBuf &b : e.reg) b.release();
     e.h_info.release(); e.h_plans.release();
     DecState &d = c->dec;
     DevBuf *db[] = {&d.info, &d.blocks, &d.chunks, &d.streams, &d.rec, &d.partials, &d.tables, &d.lz_scratch};
@@ -247,12 +246,6 @@ extern "C" int fqz_debug_get_stamps(fqz_ctx *ctx, unsigned long long *out, size_
 {
     if (!ctx || !out || !n_chunks) return FQZ_E_ARG;
     return fqz_enc_get_stamps(ctx, out, max_chunks, n_chunks);
-}
-
-extern "C" int fqz_debug_get_fs_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_tiles, size_t *n_tiles)
-{
-    if (!ctx || !out || !n_tiles) return FQZ_E_ARG;
-    return fqz_enc_get_fs_stamps(ctx, out, max_tiles, n_tiles);
 }
 
 extern "C" int fqz_debug_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_t stream_len[6])

@@ -64,26 +64,26 @@ struct EncState {
     size_t out_cap = 0;
     hipStream_t stream = nullptr;
     bool in_flight = false;
-    bool small_tiles_now = false;   // the launch in flight used 4 KiB text tiles
-    uint32_t small_tiles_left = 0;  // > 0 after a 32 KiB tile overflowed its newline list: this many launches use 4 KiB tiles
+    bool two_pass_now = false;   // the launch in flight used the two-pass index
+    uint32_t two_pass_left = 0;  // > 0 after a batch overflowed a tile-local line slot: this many launches count newlines first, then index
     // capacities
-    uint32_t n_tiles = 0, rec_cap = 0, block_cap = 0, chunk_cap = 0;
-    size_t npos_cap = 0;
+    uint32_t n_tiles = 0, line_cap = 0, rec_cap = 0, block_cap = 0, chunk_cap = 0;
+    size_t arena_cap = 0, npos_cap = 0;
     // device workspaces
     DevBuf info;      // EncInfo
-    DevBuf Enpos;     // u32[rec_cap+1]: bytes of every record in the nPos stream -> exclusive offsets
-    DevBuf rec_seq;   // u32[rec_cap]: text offset of the sequence line (k_npos_write)
-    DevBuf rec_L;     // u32[rec_cap]: read length
-    DevBuf bstart;    // FsBStart[block_cap+1]: stream offsets at the first record of every block
-    DevBuf zstate;    // look-back states and tickets of the batch (zeroed by k_init)
+    DevBuf tile_cnt;  // u32[n_tiles+1]
+    DevBuf ls;        // u32[line_cap+1] line starts
+    DevBuf lf;        // u8[line_cap+1] line flags: '\r' before the newline | first-byte class << 1
+    DevBuf E;         // u32[5][rec_cap+1]: seq, qual, hdr, plus, npos sizes -> exclusive offsets
+    DevBuf zstate;    // look-back states and tickets of the batch's scans (zeroed by k_init)
     DevBuf scan_state; // look-back states of k_scan + its ticket
     DevBuf gmap;      // chunk-group descriptors (k_group_map)
     DevBuf plans;     // BlockPlan[block_cap]
-    DevBuf reg[FQZ_NS]; // the six pre-entropy streams of the batch, one region each (every block's part back to back)
+    DevBuf arena;     // seq/qual/hdr/plus/len pre-entropy streams
+    DevBuf npos;      // nPos pre-entropy streams
     DevBuf slots;     // chunk_cap * FQZ_SLOT
     DevBuf csize;     // u32[chunk_cap+1] -> exclusive prefix
     DevBuf stamps;    // diagnostic s_memtime stamps (FQZ_DBG_STAMPS)
-    DevBuf fs_stamps; // diagnostic s_memtime stamps of k_fsplit (FQZ_DBG_FS_STAMPS): 8 per tile
     bool streams_valid = false; // an encode has run: fqz_debug_get_streams can read its streams
     PinnedBuf h_info; // EncInfo
     PinnedBuf h_plans;
@@ -174,7 +174,6 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
 int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uint64_t *block_len, size_t max_blocks);
 int fqz_enc_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_t stream_len[6]);
 int fqz_enc_get_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_chunks, size_t *n_chunks);
-int fqz_enc_get_fs_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_tiles, size_t *n_tiles);
 // fqz_decode.hip
 int fqz_dec_launch(fqz_ctx *ctx, const uint8_t *d_blocks, size_t n_bytes, uint8_t version, int qual_encoding, uint8_t *d_out,
                    size_t out_cap, hipStream_t stream);

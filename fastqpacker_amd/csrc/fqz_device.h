@@ -166,38 +166,15 @@ __device__ __forceinline__ void store_piece(uint8_t *dst, const uint32_t w[4], u
     if (nb & 1) *dst = (uint8_t)cur;
 }
 
-// keeps the first `valid` (< 16) bytes of the 16 in w[], zeroes the rest
-__device__ __forceinline__ void mask_tail16(uint32_t w[4], uint32_t valid)
-{
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-        const uint32_t have = valid > 4 * k ? valid - 4 * k : 0u; // bytes of dword k that are valid
-        w[k] = have >= 4 ? w[k] : (have ? w[k] & ((1u << (8 * have)) - 1) : 0u);
-    }
-}
-// 16 text bytes at text[off..off+16), any alignment; bytes at or beyond n_text read as 0 (only the very last lines of
-// the text get there).  `text` is 16-byte aligned, so an ALIGNED 16-byte block that holds one valid byte lies inside
-// the page of that byte: the tail is read as two aligned blocks and shifted in registers, never with a load that could
-// cross into an unmapped page, and without a byte loop (whose registers every hot loop would pay for).
+// 16 text bytes at text[off..off+16); bytes at or beyond n_text read as 0 (only the very last lines of the text get there)
 __device__ __forceinline__ void load_piece(const uint8_t *text, size_t off, size_t n_text, uint32_t w[4])
 {
     if (off + 16 <= n_text) {
         uint4 v = load_u128_unaligned(text + off);
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else if (off >= n_text) {
-        w[0] = w[1] = w[2] = w[3] = 0;
     } else {
-        const size_t a0 = off & ~(size_t)15;
-        const uint4 b0 = *(const uint4 *)(text + a0);
-        const uint4 b1 = a0 + 16 < n_text ? *(const uint4 *)(text + a0 + 16) : make_uint4(0, 0, 0, 0);
-        const uint32_t ds = (uint32_t)(off >> 2) & 3u, sh = (uint32_t)off & 3u;
-        const uint32_t e[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        uint32_t d[5]; // dwords ds .. ds + 4
-#pragma unroll
-        for (uint32_t i = 0; i < 5; i++) d[i] = ds == 0 ? e[i] : (ds == 1 ? e[i + 1] : (ds == 2 ? e[i + 2] : (i + 3 < 8 ? e[i + 3 < 8 ? i + 3 : 7] : 0u)));
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) w[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
-        mask_tail16(w, (uint32_t)(n_text - off));
+        w[0] = w[1] = w[2] = w[3] = 0;
+        for (uint32_t b = 0; b < 16 && off + b < n_text; b++) w[b >> 2] |= (uint32_t)text[off + b] << (8 * (b & 3));
     }
 }
 

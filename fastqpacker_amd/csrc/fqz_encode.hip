@@ -1,9 +1,9 @@
 // fqz_encode.hip — device-resident encode pipeline (gfx950 / MI355X).
 //
 // Replaces, for a batch of blocks at once, the reference's
-//   fqparser.nextInto/readLine            internal/fqparser/parser.go:136-243   (k_fsplit, fqz_fsplit.h)
-//   encoder.DetectEncoding                internal/encoder/quality.go:22-49     (k_fsplit, mode 1)
-//   compressBlockWithBuffers record loop  internal/compress/compress.go:474-520 (k_fsplit, k_npos_write)
+//   fqparser.nextInto/readLine            internal/fqparser/parser.go:136-243   (k_count_nl, k_line_starts, k_record_scan)
+//   encoder.DetectEncoding                internal/encoder/quality.go:22-49     (k_detect)
+//   compressBlockWithBuffers record loop  internal/compress/compress.go:474-520 (k_split, k_npos_write)
 //     encoder.AppendPackedBases           internal/encoder/sequence.go:139-184
 //     encoder.NormalizeQuality+DeltaEncode internal/encoder/quality.go:53-103
 //   6 x zstd.Encoder.EncodeAll            compress.go:523-528                   (k_entropy: Huffman-literal zstd blocks)
@@ -113,7 +113,7 @@ static int launch_scan(fqz_ctx *ctx, const char *label, hipStream_t st, uint32_t
 }
 
 // ===========================================================================
-// batch state
+// K0 line index (parser.go:209-243 readLine)
 // ===========================================================================
 __global__ __launch_bounds__(256) void k_init(EncInfo *info, int qual_encoding, unsigned long long *zstate, uint32_t zwords)
 {
@@ -124,28 +124,386 @@ __global__ __launch_bounds__(256) void k_init(EncInfo *info, int qual_encoding, 
         z.error_key = ~0ull;
         z.min_qual = 255;
         z.qual_off = qual_encoding == FQZ_ENCODING_PHRED64 ? 64 : 33;
-        z.detect_done_tile = 0xFFFFFFFFu;
         *info = z;
     }
 }
 
-// 16 text bytes at offset off (off and text 16-byte aligned); bytes at or beyond n read as 0.  An aligned 16-byte block
-// that holds a valid byte never leaves that byte's page, so the block is always loaded whole and masked in registers.
+// 16 text bytes of thread t in tile; bytes at or beyond n read as 0
 __device__ __forceinline__ uint4 load_text16(const uint8_t *text, uint32_t off, uint32_t n)
 {
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (off < n) {
+    if (off + 16 <= n) {
         v = *(const uint4 *)(text + off);
-        if (off + 16 > n) {
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            mask_tail16(w, n - off);
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-        }
+    } else if (off < n) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; off + k < n; k++) w[k >> 2] |= (uint32_t)text[off + k] << (8 * (k & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
     }
     return v;
 }
 
-#include "fqz_fsplit.h"
+__global__ __launch_bounds__(256) void k_count_nl(const uint8_t *text, uint32_t n, uint32_t *tile_cnt)
+{
+    __shared__ uint32_t sh[4];
+    uint32_t off = blockIdx.x * FQZ_TILE + threadIdx.x * 16;
+    uint4 v = load_text16(text, off, n);
+    uint32_t c = count_newlines(v.x) + count_newlines(v.y) + count_newlines(v.z) + count_newlines(v.w);
+    uint32_t tot;
+    (void)block_excl_scan_256(c, sh, &tot);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+}
+
+// Line index + line flags.  Newline j (1-based) ends line j-1 and starts line j:
+//   ls[j] = text offset of line j;  lf[j] = (byte before the newline is '\r') | class of line j's first byte << 1
+// (class 1 = '@', 2 = '+', 0 = anything else / no byte).  With them the record table never touches the text again.
+// A workgroup handles four consecutive 4 KiB tiles (16 bytes per thread each, coalesced); the four per-thread
+// newline counts are scanned together, packed 2 x 16 bits, and every tile adds its own base from the tile scan.
+// The bytes either side of a newline come from registers (neighbouring threads' edge bytes through LDS).
+#define LI_SUB 4u
+// Two-pass index (fallback, see k_line_local): needs the scanned per-tile newline counts (k_count_nl + k_scan) first.
+__global__ __launch_bounds__(256) void k_line_starts(const uint8_t *__restrict__ text, uint32_t n, uint32_t n_tiles, const uint32_t *__restrict__ tile_off,
+                                                     uint32_t *__restrict__ ls, uint8_t *__restrict__ lf, uint32_t line_cap)
+{
+    __shared__ uint32_t sh_lo[4], sh_hi[4], s_ext[2];
+    __shared__ uint16_t edge[LI_SUB][258]; // [q][t + 1] = first byte | last byte << 8 of thread t's 16 bytes of tile q
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const uint32_t tile0 = blockIdx.x * LI_SUB;
+    const uint32_t base = tile0 * FQZ_TILE;
+    uint32_t w[LI_SUB][4], m[LI_SUB][4], c[LI_SUB];
+#pragma unroll
+    for (uint32_t q = 0; q < LI_SUB; q++) {
+        const uint4 v = load_text16(text, base + q * FQZ_TILE + 16 * t, n);
+        w[q][0] = v.x; w[q][1] = v.y; w[q][2] = v.z; w[q][3] = v.w;
+    }
+    if (t == 0) s_ext[0] = base ? text[base - 1] : 0;
+    if (t == 255) s_ext[1] = (size_t)base + LI_SUB * FQZ_TILE < n ? text[base + LI_SUB * FQZ_TILE] : 0;
+#pragma unroll
+    for (uint32_t q = 0; q < LI_SUB; q++) {
+        c[q] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { m[q][k] = zero_bytes(w[q][k] ^ 0x0A0A0A0Au); c[q] += __popc(m[q][k]); }
+        edge[q][t + 1] = (uint16_t)((w[q][0] & 0xFF) | ((w[q][3] >> 24) << 8));
+    }
+    // ---- workgroup scan of the four per-tile counts, packed 2 x 16 bits (a tile holds <= 4096 newlines)
+    const uint32_t lo = c[0] | (c[1] << 16), hi = c[2] | (c[3] << 16);
+    const uint32_t incl_lo = wave_incl_scan(lo), incl_hi = wave_incl_scan(hi);
+    if (lane == 63) { sh_lo[wave] = incl_lo; sh_hi[wave] = incl_hi; }
+    __syncthreads(); // (also publishes edge[] and s_ext[])
+    uint32_t base_lo = 0, base_hi = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+        if (k < wave) { base_lo += sh_lo[k]; base_hi += sh_hi[k]; }
+    const uint32_t ex_lo = base_lo + incl_lo - lo, ex_hi = base_hi + incl_hi - hi; // exclusive, per tile
+    const uint32_t sub_excl[LI_SUB] = {ex_lo & 0xFFFF, ex_lo >> 16, ex_hi & 0xFFFF, ex_hi >> 16};
+    if (blockIdx.x == 0 && t == 0) {
+        ls[0] = 0;
+        lf[0] = (uint8_t)(n ? (((w[0][0] & 0xFF) == '@' ? 1 : (w[0][0] & 0xFF) == '+' ? 2 : 0) << 1) : 0);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < LI_SUB; q++) {
+        if (!c[q]) continue; // (tiles at or beyond n_tiles are empty)
+        uint32_t idx = tile_off[tile0 + q] + sub_excl[q];
+        const uint32_t off = base + q * FQZ_TILE + 16 * t;
+        const uint32_t prev_b = t ? (uint32_t)(edge[q][t] >> 8) : (q ? (uint32_t)(edge[q ? q - 1 : 0][256] >> 8) : s_ext[0]);
+        const uint32_t next_b = t < 255 ? (uint32_t)(edge[q][t + 2] & 0xFF) : (q + 1 < LI_SUB ? (uint32_t)(edge[q + 1 < LI_SUB ? q + 1 : q][1] & 0xFF) : s_ext[1]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t mk = m[q][k];
+            while (mk) {
+                const int bit = __ffs(mk) - 1; // 7, 15, 23, 31
+                mk &= mk - 1;
+                const uint32_t b = (uint32_t)bit >> 3;
+                const uint32_t before = b ? (w[q][k] >> (8 * b - 8)) & 0xFF : (k ? w[q][k ? k - 1 : 0] >> 24 : prev_b);
+                const uint32_t after = b < 3 ? (w[q][k] >> (8 * b + 8)) & 0xFF : (k < 3 ? w[q][k < 3 ? k + 1 : 3] & 0xFF : next_b);
+                idx++;
+                if (idx <= line_cap) {
+                    ls[idx] = off + 4 * k + b + 1; // line idx starts after newline idx
+                    lf[idx] = (uint8_t)((before == '\r' ? 1 : 0) | (after == '@' ? 2 : after == '+' ? 4 : 0));
+                }
+            }
+        }
+    }
+}
+
+
+// The default path reads the text ONCE.  Nothing is known about the tiles before this one, so a tile's entries go to its
+// own slot of LL_CAP entries (lsl / lfl, tile-local index) and its newline count to tile_cnt; after the scan of the
+// counts k_line_gather moves the entries to their global places (57 MB instead of a second pass over the text to count
+// newlines first).  A tile with more than LL_CAP lines (lines under 8 bytes on average) raises info->index_overflow and
+// the batch is redone with the two-pass path (k_count_nl, scan, k_line_starts).
+// One WAVE per 4 KiB tile (four rows of 64 x 16 bytes), no workgroup barrier: the per-lane newline counts of the four
+// rows are scanned together (packed 2 x 16 bits), then every newline's tile-local position is dropped into a list in
+// LDS (a short divergent loop: nothing but find-first-set and a 2-byte store), and the list - ~47 entries for 150 bp
+// reads - is turned into (line start, flags) entries by consecutive lanes: dense stores, and the bytes either side of
+// the newline are two L1-hot byte loads.
+#define LL_CAP 512u
+__global__ __launch_bounds__(256) void k_line_local(const uint8_t *__restrict__ text, uint32_t n, uint32_t n_tiles, uint32_t *__restrict__ ls,
+                                                    uint8_t *__restrict__ lf, uint32_t *__restrict__ lsl, uint8_t *__restrict__ lfl,
+                                                    uint32_t *__restrict__ tile_cnt, EncInfo *info)
+{
+    __shared__ uint16_t s_pos[4][LL_CAP];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t tile = blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return; // (whole waves leave; the kernel has no workgroup barrier)
+    const uint32_t tbase = tile * FQZ_TILE;
+    uint32_t m[4][4], c[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint4 v = load_text16(text, tbase + q * 1024 + 16 * lane, n);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        c[q] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { m[q][k] = zero_bytes(w[k] ^ 0x0A0A0A0Au); c[q] += __popc(m[q][k]); }
+        if (tile == 0 && q == 0 && lane == 0) {
+            ls[0] = 0;
+            lf[0] = (uint8_t)(n ? (((v.x & 0xFF) == '@' ? 1 : (v.x & 0xFF) == '+' ? 2 : 0) << 1) : 0);
+        }
+    }
+    // exclusive prefix of the counts in text order (row-major), packed 2 x 16 bits (a row holds <= 1024 newlines)
+    const uint32_t lo = c[0] | (c[1] << 16), hi = c[2] | (c[3] << 16);
+    const uint32_t incl_lo = wave_incl_scan(lo), incl_hi = wave_incl_scan(hi);
+    const uint32_t tot_lo = (uint32_t)__builtin_amdgcn_readlane((int)incl_lo, 63), tot_hi = (uint32_t)__builtin_amdgcn_readlane((int)incl_hi, 63);
+    const uint32_t rb1 = tot_lo & 0xFFFF, rb2 = rb1 + (tot_lo >> 16), rb3 = rb2 + (tot_hi & 0xFFFF), total = rb3 + (tot_hi >> 16);
+    const uint32_t ex_lo = incl_lo - lo, ex_hi = incl_hi - hi;
+    const uint32_t excl[4] = {ex_lo & 0xFFFF, rb1 + (ex_lo >> 16), rb2 + (ex_hi & 0xFFFF), rb3 + (ex_hi >> 16)};
+    if (lane == 0) {
+        tile_cnt[tile] = total;
+        if (total > LL_CAP) atomicOr(&info->index_overflow, 1u);
+    }
+    // ---- tile-local position of every newline -> list
+    uint16_t *list = s_pos[wave];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        uint32_t idx = excl[q];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t mk = m[q][k];
+            while (mk) {
+                const uint32_t bit = (uint32_t)__ffs(mk) - 1; // 7, 15, 23, 31
+                mk &= mk - 1;
+                if (idx < LL_CAP) list[idx] = (uint16_t)(q * 1024 + 16 * lane + 4 * k + (bit >> 3));
+                idx++;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- list -> entries: line j + 1 of the tile starts after newline j; flags as in k_line_starts
+    const uint32_t cnt = total < LL_CAP ? total : LL_CAP;
+    for (uint32_t j = lane; j < cnt; j += 64) {
+        const uint32_t p = tbase + list[j];
+        const uint32_t before = p ? text[p - 1] : 0u, after = p + 1 < n ? text[p + 1] : 0u;
+        lsl[(size_t)tile * LL_CAP + j] = p + 1;
+        lfl[(size_t)tile * LL_CAP + j] = (uint8_t)((before == '\r' ? 1 : 0) | (after == '@' ? 2 : after == '+' ? 4 : 0));
+    }
+}
+
+// tile-local line entries -> ls / lf: entry j of a tile is newline tile_off[tile] + j + 1 of the text.  A workgroup takes
+// 16 tiles and a thread one global entry at a time, so the writes are dense; the tile of an entry comes from a 4-step
+// search over the workgroup's 17 offsets.
+#define LG_TILES 16u
+__global__ __launch_bounds__(256) void k_line_gather(const uint32_t *__restrict__ tile_off, uint32_t n_tiles, const uint32_t *__restrict__ lsl,
+                                                     const uint8_t *__restrict__ lfl, uint32_t *__restrict__ ls, uint8_t *__restrict__ lf, uint32_t line_cap)
+{
+    __shared__ uint32_t so[LG_TILES + 1];
+    const uint32_t t0 = blockIdx.x * LG_TILES;
+    if (threadIdx.x <= LG_TILES) {
+        const uint32_t i = t0 + threadIdx.x;
+        so[threadIdx.x] = tile_off[i < n_tiles ? i : n_tiles];
+    }
+    __syncthreads();
+    const uint32_t first = so[0], total = so[LG_TILES] - first;
+    for (uint32_t e = threadIdx.x; e < total; e += 256) {
+        const uint32_t g = first + e; // newline g + 1 of the text
+        uint32_t k = 0;
+        if (so[k + 8] <= g) k += 8;
+        if (so[k + 4] <= g) k += 4;
+        if (so[k + 2] <= g) k += 2;
+        if (so[k + 1] <= g) k += 1;
+        const uint32_t j = g - so[k];
+        if (j < LL_CAP && g < line_cap) {
+            ls[g + 1] = lsl[(size_t)(t0 + k) * LL_CAP + j];
+            lf[g + 1] = lfl[(size_t)(t0 + k) * LL_CAP + j];
+        }
+    }
+}
+
+// ===========================================================================
+// record table (parser.go:136-183 nextInto) and block plan
+// ===========================================================================
+__global__ void k_setup_records(EncInfo *info, const uint32_t *tile_off, uint32_t n_tiles, const uint32_t *ls, uint32_t line_cap,
+                                uint32_t rec_cap, uint32_t block_cap, uint32_t rpb, uint32_t final_batch, uint32_t n_bytes)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t n_lines = tile_off[n_tiles];
+    info->n_lines = n_lines;
+    if (n_lines > line_cap || info->index_overflow) { info->status = FQZ_E_TOO_LARGE; info->n_rec = 0; info->n_blocks = 0; return; }
+    uint32_t total = n_lines / 4;
+    uint32_t n_rec = final_batch ? total : (total / rpb) * rpb;
+    uint32_t n_blocks = (n_rec + rpb - 1) / rpb;
+    if (n_rec > rec_cap || n_blocks > block_cap) { info->status = FQZ_E_TOO_LARGE; n_rec = 0; n_blocks = 0; }
+    info->n_rec_total = total;
+    info->n_rec = n_rec;
+    info->n_blocks = n_blocks;
+    info->consumed = final_batch ? n_bytes : ls[4 * n_rec];
+}
+
+// line k of record r: [start, start+len) with the trailing '\r' stripped (parser.go:213-215)
+__device__ __forceinline__ void line_span(const uint8_t *text, const uint32_t *ls, uint32_t line, uint32_t *start, uint32_t *len)
+{
+    uint32_t s = ls[line], e = ls[line + 1] - 1; // e = position of '\n'
+    uint32_t l = e - s;
+    if (l > 0 && text[e - 1] == '\r') l--;
+    *start = s;
+    *len = l;
+}
+
+// Record table in one pass: validation (parser.go:136-183), per-record stream sizes, and their exclusive prefix sums
+// (the offsets of every record in the seq / qual / headers / plus streams), all from the line index and line flags.
+// A workgroup owns 4096 records (a wave 1024 consecutive ones, 16 coalesced rows of 64).  The sums of the tiles before it come from a
+// decoupled look-back (wave w resolves column w); tiles are handed out by an atomic ticket so that every predecessor
+// of a running tile is running or done.  state[tile][column] = flag << 62 | value (1 = tile sum, 2 = inclusive
+// prefix).  Large tiles keep the look-back chain short (the prefix front advances 64 tiles per memory round trip);
+// the record sizes are computed twice (sums, then offsets) rather than kept in 64 registers.
+#ifndef RS_PER
+#define RS_PER 16u
+#endif
+#define RS_TILE (256u * RS_PER)
+#define RS_AGG (1ull << 62)
+#define RS_PREFIX (2ull << 62)
+#define RS_VALUE ((1ull << 62) - 1)
+// sizes of record r (< n_rec) in the four streams; reports its format errors when `check`
+__device__ __forceinline__ void record_sizes(const uint32_t *__restrict__ ls, const uint8_t *__restrict__ lf, EncInfo *info, uint32_t r, bool check,
+                                             uint32_t out[4])
+{
+    const uint4 s4 = *(const uint4 *)(ls + 4 * (size_t)r); // ls is 16-byte aligned
+    const uint32_t s_next = ls[4 * (size_t)r + 4];
+    const uint32_t f4 = *(const uint32_t *)(lf + 4 * (size_t)r), f_next = lf[4 * (size_t)r + 4];
+    // length without '\n' and without one trailing '\r' (the flag implies a non-empty line)
+    uint32_t l0 = s4.y - 1 - s4.x - ((f4 >> 8) & 1);
+    uint32_t l1 = s4.z - 1 - s4.y - ((f4 >> 16) & 1);
+    uint32_t l2 = s4.w - 1 - s4.z - ((f4 >> 24) & 1);
+    uint32_t l3 = s_next - 1 - s4.w - (f_next & 1);
+    if (l0 == 0 || ((f4 >> 1) & 3) != 1) { if (check) report_error(info, r, 0, FQZ_E_HDR_AT); l0 = 1; }
+    if (l2 == 0 || ((f4 >> 17) & 3) != 2) { if (check) report_error(info, r, 1, FQZ_E_SEP_PLUS); l2 = 1; }
+    if (check && l1 != l3) report_error(info, r, 2, FQZ_E_LEN_MISMATCH);
+    uint32_t H = l0 - 1, P = l2 - 1;
+    if (H > 65535u || P > 65535u) { if (check) report_error(info, r, 3, FQZ_E_FIELD_WRAP); H &= 0xFFFF; P &= 0xFFFF; }
+    out[S_SEQ] = (l1 + 3) >> 2;
+    out[S_QUAL] = l1;
+    out[S_HDR] = 2 + H;
+    out[S_PLUS] = 2 + P;
+}
+
+__global__ __launch_bounds__(256) void k_record_scan(const uint32_t *__restrict__ ls, const uint8_t *__restrict__ lf, EncInfo *info, uint32_t *__restrict__ E,
+                                                     uint32_t estride, uint32_t final_batch, unsigned long long *state, uint32_t *ticket)
+{
+    __shared__ uint32_t s_tile, shw[4][4], s_excl[4];
+    const uint32_t n_rec = info->n_rec, n_lines = info->n_lines;
+    if ((unsigned long long)blockIdx.x * RS_TILE > n_rec) return; // exactly the tiles that hold a record index <= n_rec take a ticket
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    if (t == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    // wave w owns the records [rw, rw + 64 * RS_PER): row j = records rw + 64 j + lane (coalesced loads and stores)
+    const uint32_t rw = tile * RS_TILE + wave * (64 * RS_PER);
+    uint32_t tsum[4] = {0, 0, 0, 0};
+    for (uint32_t j = 0; j < RS_PER; j++) {
+        const uint32_t r = rw + 64 * j + lane;
+        if (r < n_rec) {
+            uint32_t v[4];
+            record_sizes(ls, lf, info, r, true, v);
+#pragma unroll
+            for (int c = 0; c < 4; c++) tsum[c] += v[c];
+        } else if (r == n_rec && final_batch && info->status == 0) {
+            // a trailing partial record (final batch only): the lines that exist are still
+            // validated before EOF is hit (parser.go:138-165), then it is dropped (parser.go:196-199)
+            uint32_t have = n_lines - 4 * n_rec; // 0..3 complete lines
+            if (have >= 1 && (lf[4 * (size_t)r] >> 1) != 1) report_error(info, r, 0, FQZ_E_HDR_AT);
+            if (have >= 3 && (lf[4 * (size_t)r + 2] >> 1) != 2) report_error(info, r, 1, FQZ_E_SEP_PLUS);
+        }
+    }
+    // ---- totals per wave, then per workgroup
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t ws = wave_sum(tsum[c]);
+        if (lane == 0) shw[wave][c] = ws;
+    }
+    __syncthreads();
+    uint32_t wbase[4], btot[4]; // sum of the waves before this one, tile total
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint32_t base = 0, tot = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { if (k < wave) base += shw[k][c]; tot += shw[k][c]; }
+        wbase[c] = base;
+        btot[c] = tot;
+    }
+    // ---- decoupled look-back: wave w resolves column w
+    {
+        const uint32_t c = wave;
+        const uint32_t tot = c == 0 ? btot[0] : c == 1 ? btot[1] : c == 2 ? btot[2] : btot[3];
+        unsigned long long excl = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(&state[(size_t)tile * 4 + c], RS_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int look = (int)tile - 1;
+            for (;;) {
+                const int idx = look - (int)lane;
+                const unsigned long long sv = idx >= 0 ? __hip_atomic_load(&state[(size_t)idx * 4 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_PREFIX;
+                const uint32_t flag = (uint32_t)(sv >> 62);
+                const unsigned long long pmask = __ballot(flag == 2), zmask = __ballot(flag == 0);
+                const int fp = pmask ? __ffsll((long long)pmask) - 1 : 64;          // nearest predecessor with a full prefix
+                const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1); // lanes 0..fp must have published
+                if (zmask & need) { __builtin_amdgcn_s_sleep(2); continue; }
+                unsigned long long part = (int)lane <= fp ? (sv & RS_VALUE) : 0ull;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, WAVE);
+                excl += part;
+                if (pmask) break;
+                look -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&state[(size_t)tile * 4 + c], RS_PREFIX | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl[c] = (uint32_t)excl; // stream offsets inside a batch fit 32 bits (checked by k_plan1)
+        }
+    }
+    __syncthreads();
+    // ---- offsets: row by row, a wave scan per column with the running sum carried in a wave-uniform register
+    uint32_t carry[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) carry[c] = s_excl[c] + wbase[c];
+    for (uint32_t j = 0; j < RS_PER; j++) {
+        const uint32_t r = rw + 64 * j + lane;
+        if (rw + 64 * j > n_rec) break; // (wave-uniform)
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (r < n_rec) {
+            record_sizes(ls, lf, info, r, false, v); // (line index and flags come from L2 this time)
+            E[(size_t)S_NPOS * estride + r] = 2;     // u16 count; the sequence stage adds 2 bytes per N position
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t inc = wave_incl_scan(v[c]);
+            if (r <= n_rec) E[(size_t)c * estride + r] = carry[c] + inc - v[c]; // [n_rec] = total
+            carry[c] += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+    }
+}
+
+// encoder.DetectEncoding (quality.go:22-49) over the first block: min quality byte
+__global__ __launch_bounds__(256) void k_detect(const uint8_t *text, const uint32_t *ls, EncInfo *info, uint32_t rpb)
+{
+    uint32_t n_rec = info->n_rec < rpb ? info->n_rec : rpb;
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    uint32_t mn = 255;
+    for (uint32_t r = wave; r < n_rec; r += nwaves) {
+        uint32_t s, l;
+        line_span(text, ls, 4 * r + 3, &s, &l);
+        for (uint32_t i = lane; i < l; i += WAVE) { uint32_t b = text[s + i]; mn = b < mn ? b : mn; }
+    }
+    mn = wave_min(mn);
+    if (lane == 0 && mn < 255) atomicMin(&info->min_qual, mn);
+}
 
 __global__ void k_finish_detect(EncInfo *info)
 {
@@ -155,63 +513,43 @@ __global__ void k_finish_detect(EncInfo *info)
     info->qual_off = (mn != 255 && mn >= 64) ? 64 : 33;
 }
 
-// ===========================================================================
-// batch plan: which records are encoded, where every block's streams lie (one 256-thread workgroup)
-// ===========================================================================
-struct FsCaps { unsigned long long cap[4]; }; // capacities of the seq / qual / headers / plus regions
-
-__global__ __launch_bounds__(256) void k_fplan(EncInfo *info, const FsBStart *bstart, BlockPlan *plans, uint32_t n_bytes, uint32_t rpb, uint32_t final_batch,
-                                               uint32_t rec_cap, uint32_t block_cap, FsCaps caps, uint32_t main_cap)
+// arena layout of the streams whose sizes are known after the first scans: one thread per block, offsets and
+// chunk ids by a workgroup scan (launch with one 256-thread workgroup)
+__global__ __launch_bounds__(256) void k_plan1(EncInfo *info, const uint32_t *E, uint32_t estride, BlockPlan *plans, uint32_t rpb, size_t arena_cap,
+                                               uint32_t main_cap)
 {
     __shared__ uint32_t sh[8], s_stop;
     const uint32_t t = threadIdx.x;
     if (t == 0) {
-        const uint32_t n_lines = info->n_lines;
-        const uint32_t total = n_lines / 4;                                // whole records present
-        uint32_t n_rec = final_batch ? total : (total / rpb) * rpb;       // a batch that is not the last one ends on a block boundary
-        uint32_t n_blocks = (n_rec + rpb - 1) / rpb;
-        info->n_rec_total = total;
-        int32_t status = 0;
-        if (info->index_overflow || total > rec_cap || n_blocks > block_cap) status = FQZ_E_TOO_LARGE;
-        for (int q = 0; q < 4; q++) if (info->tot[q] > caps.cap[q] || info->tot[q] > 0xFFFFFFF0ull) status = FQZ_E_TOO_LARGE;
-        if (!status && info->error_key != ~0ull) {
-            // records behind the last whole block of a non-final batch are parsed again with the next batch: not their error yet
-            const uint32_t rec = (uint32_t)(info->error_key >> 8);
-            if (final_batch || rec < n_rec) { status = -(int32_t)(info->error_key & 31); info->error_record = rec; }
+        if (info->error_key != ~0ull && info->status == 0) {
+            info->status = -(int32_t)(info->error_key & 31);
+            info->error_record = (uint32_t)(info->error_key >> 8);
         }
-        info->error_key = ~0ull; // later stages report through the same key (k_npos_write)
-        if (status) { n_rec = 0; n_blocks = 0; }
-        info->status = status;
-        info->n_rec = n_rec;
-        info->n_blocks = n_blocks;
-        info->consumed = final_batch ? n_bytes : (n_rec ? bstart[n_rec / rpb].text : 0u);
-        s_stop = status != 0;
+        s_stop = info->status != 0;
+        if (s_stop) { info->n_blocks = 0; info->n_rec = 0; }
     }
     __syncthreads();
     if (s_stop) return;
     const uint32_t n_rec = info->n_rec, n_blocks = info->n_blocks;
     const int order[5] = {S_SEQ, S_QUAL, S_HDR, S_PLUS, S_LEN};
-    uint32_t carry_ch = 0;
+    uint32_t carry_a16 = 0, carry_ch = 0; // arena offset in 16-byte units, chunk id
+    bool overflow = false;
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += 256) {
         const uint32_t b = b0 + t;
-        uint32_t len[5] = {0, 0, 0, 0, 0}, st[4] = {0, 0, 0, 0}, ch = 0, r0 = 0, r1 = 0;
+        uint32_t len[5] = {0, 0, 0, 0, 0}, a16 = 0, ch = 0, r0 = 0, r1 = 0;
         if (b < n_blocks) {
             r0 = b * rpb;
             r1 = r0 + rpb < n_rec ? r0 + rpb : n_rec;
-            const FsBStart bs = bstart[b];
-            // the next block's first record exists (its header line at least) unless this block is the short last one
-            const bool whole = r1 == r0 + rpb;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                st[q] = bs.e[q];
-                const uint32_t en = whole ? bstart[b + 1].e[q] : (uint32_t)info->tot[q];
-                len[q] = en - st[q];
+            for (int q = 0; q < 5; q++) {
+                const int s = order[q];
+                len[q] = s == S_LEN ? 4 * (r1 - r0) : E[(size_t)s * estride + r1] - E[(size_t)s * estride + r0];
+                a16 += (len[q] + 15) >> 4;
                 ch += (len[q] + FQZ_CHUNK - 1) / FQZ_CHUNK;
             }
-            len[4] = 4 * (r1 - r0);
-            ch += (len[4] + FQZ_CHUNK - 1) / FQZ_CHUNK;
         }
-        uint32_t tot_c;
+        uint32_t tot_a, tot_c;
+        uint32_t ex_a = carry_a16 + block_excl_scan_256(a16, sh, &tot_a);
         uint32_t ex_c = carry_ch + block_excl_scan_256(ch, sh + 4, &tot_c);
         if (b < n_blocks) {
             BlockPlan *p = &plans[b];
@@ -221,126 +559,236 @@ __global__ __launch_bounds__(256) void k_fplan(EncInfo *info, const FsBStart *bs
             for (int q = 0; q < 5; q++) {
                 const int s = order[q];
                 p->len[s] = len[q];
-                p->a_off[s] = q < 4 ? st[q] : 4 * r0; // offset inside the stream's region
-                p->chunk_base[s] = ex_c;               // main chunk ids: block by block, in this stream order
+                p->a_off[s] = ex_a << 4;
+                ex_a += (len[q] + 15) >> 4;
+                p->chunk_base[s] = ex_c; // main chunk ids: block by block, in this stream order
                 ex_c += (len[q] + FQZ_CHUNK - 1) / FQZ_CHUNK;
                 atomicAdd(&info->stream_raw[s], (unsigned long long)len[q]);
             }
             p->orig_seq = len[1];
         }
+        if ((unsigned long long)carry_a16 + tot_a > 0x0FFFFFFFull) overflow = true;
+        carry_a16 += tot_a;
         carry_ch += tot_c;
     }
     if (t == 0) {
-        if (carry_ch > main_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; info->n_rec = 0; return; }
+        const unsigned long long a = (unsigned long long)carry_a16 << 4;
+        if (overflow || a > arena_cap || a > 0xFFFFFFF0ull || carry_ch > main_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; info->n_rec = 0; return; }
+        info->arena_used = (uint32_t)a;
         info->n_main = carry_ch;
         info->n_chunks = carry_ch;
     }
 }
 
-// nPos stream of every block + its chunks once the N counts are scanned (one 256-thread workgroup)
-__global__ __launch_bounds__(256) void k_plan2(EncInfo *info, const uint32_t *Enpos, BlockPlan *plans, uint32_t chunk_cap)
+// nPos arena + chunk table once the N counts are scanned (one 256-thread workgroup)
+__global__ __launch_bounds__(256) void k_plan2(EncInfo *info, const uint32_t *E, uint32_t estride, BlockPlan *plans, size_t npos_cap, uint32_t chunk_cap)
 {
     __shared__ uint32_t sh[8];
     const uint32_t t = threadIdx.x;
+    if (t == 0 && info->error_key != ~0ull && info->status == 0) {
+        info->status = -(int32_t)(info->error_key & 31);
+        info->error_record = (uint32_t)(info->error_key >> 8);
+        info->n_blocks = 0;
+    }
+    __syncthreads();
     const uint32_t n_blocks = info->n_blocks;
-    uint32_t carry_ch = info->n_main;
+    uint32_t carry_a16 = 0, carry_ch = info->n_main;
+    bool overflow = false;
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += 256) {
         const uint32_t b = b0 + t;
-        uint32_t len = 0, start = 0;
+        uint32_t len = 0;
         if (b < n_blocks) {
             const uint32_t r0 = plans[b].rec0, r1 = r0 + plans[b].nrec;
-            start = Enpos[r0];
-            len = Enpos[r1] - start;
+            len = E[(size_t)S_NPOS * estride + r1] - E[(size_t)S_NPOS * estride + r0];
         }
-        uint32_t tot_c;
+        uint32_t tot_a, tot_c;
+        const uint32_t ex_a = carry_a16 + block_excl_scan_256((len + 15) >> 4, sh, &tot_a);
         const uint32_t ex_c = carry_ch + block_excl_scan_256((len + FQZ_CHUNK - 1) / FQZ_CHUNK, sh + 4, &tot_c);
         if (b < n_blocks) {
             BlockPlan *p = &plans[b];
-            p->len[S_NPOS] = len;       // (the region holds the worst case: 2 bytes per record + 2 per base)
-            p->a_off[S_NPOS] = start;
+            p->len[S_NPOS] = len;
+            p->a_off[S_NPOS] = ex_a << 4;
             p->chunk_base[S_NPOS] = ex_c; // nPos chunk ids follow all main chunks
             atomicAdd(&info->stream_raw[S_NPOS], (unsigned long long)len);
         }
+        if ((unsigned long long)carry_a16 + tot_a > 0x0FFFFFFFull) overflow = true;
+        carry_a16 += tot_a;
         carry_ch += tot_c;
     }
     if (t == 0) {
-        if (carry_ch > chunk_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; info->n_main = 0; carry_ch = 0; }
-        info->n_chunks = carry_ch;
+        const unsigned long long a = (unsigned long long)carry_a16 << 4;
+        uint32_t chunks = carry_ch;
+        if (overflow || a > npos_cap || chunks > chunk_cap) { info->status = FQZ_E_TOO_LARGE; info->n_blocks = 0; chunks = 0; info->n_main = 0; }
+        info->npos_used = (uint32_t)a;
+        info->n_chunks = chunks;
     }
 }
 
+// ===========================================================================
+// K1..K4 the record loop of compressBlockWithBuffers (compress.go:474-520):
+//   k_split     : 2-bit pack + N count (sequence.go:139-184), quality delta (quality.go:53-103),
+//                 headers, plus lines, lengths (compress.go:495-519)
+//   k_npos_write: the N positions of the (rare) reads that have any, once their total is scanned
+// ===========================================================================
 #define RL(v, i) __builtin_amdgcn_readlane((int)(v), (i))
-// N positions: u16 count + ascending u16 positions per record (compress.go:477-488, 495-498).  Enpos has been scanned:
-// Enpos[r] = offset of record r in the nPos region.
-__global__ __launch_bounds__(256) void k_npos_write(const uint8_t *text, uint32_t n_text, EncInfo *info, const uint32_t *Enpos, const uint32_t *rec_seq,
-                                                    const uint32_t *rec_L, uint8_t *npos_arena)
+
+// ---------------------------------------------------------------------------------------------
+// Piece-centric split: a wave takes 64 records; their bases, qualities, header and plus payloads are cut into
+// 16-byte pieces of ONE text line each, and every lane of every round handles one piece: 16 text bytes in (unaligned
+// 128-bit load), 4 packed / 16 delta-coded / 16 copied bytes out.  All lanes are busy whatever the read length and a
+// wave-wide load covers ~1 KiB of text.  The piece -> record map is a binary search over a wave scan of the per-record
+// piece counts (ds_bpermute, no LDS allocation).  The nPos payload (rare) is written later by k_npos_write.
+// ---------------------------------------------------------------------------------------------
+#ifndef SPLIT_ROUNDS
+#define SPLIT_ROUNDS 2u // rounds of 64 pieces per trip (4 measured the same: 0.456 vs 0.459 ms)
+#endif
+__global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text, uint32_t n_text, const uint32_t *__restrict__ ls, EncInfo *info,
+                                               uint32_t *E, uint32_t estride, const BlockPlan *__restrict__ plans, uint32_t rpb,
+                                               uint8_t *__restrict__ arena)
 {
-    const uint32_t n_rec = info->n_rec;
-    if (info->status) return;
+    const uint32_t n_rec = info->n_rec, qoff = info->qual_off;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    const uint32_t *Eseq = E + (size_t)S_SEQ * estride, *Equal = E + (size_t)S_QUAL * estride, *Ehdr = E + (size_t)S_HDR * estride;
+    const uint32_t *Eplus = E + (size_t)S_PLUS * estride;
+    uint32_t *Enpos = E + (size_t)S_NPOS * estride;
     const uint32_t n_groups = (n_rec + 63) >> 6;
     for (uint32_t g = wave; g < n_groups; g += nwaves) {
         const uint32_t r = g * 64 + lane;
-        uint32_t s_seq = 0, L = 0, NN = 0, d_npos = 0;
+        uint32_t s_hdr = 0, s_seq = 0, s_plus = 0, s_qual = 0, L = 0, H = 0, P = 0;
+        uint32_t d_seq = 0, d_qual = 0, d_hdr = 0, d_plus = 0;
         if (r < n_rec) {
-            d_npos = Enpos[r];
-            NN = (Enpos[r + 1] - d_npos - 2) >> 1;
-            uint8_t *dn = npos_arena + d_npos;
-            if (NN > 65535u) { report_error(info, r, 5, FQZ_E_FIELD_WRAP); NN = 0; }
-            dn[0] = (uint8_t)NN; dn[1] = (uint8_t)(NN >> 8);
-            if (NN) { s_seq = rec_seq[r]; L = rec_L[r]; }
+            const uint4 l4 = *(const uint4 *)(ls + 4 * (size_t)r); // starts of the record's four lines
+            s_hdr = l4.x + 1; s_seq = l4.y; s_plus = l4.z + 1; s_qual = l4.w;
+            const BlockPlan *p = &plans[r / rpb];
+            const uint32_t r0 = p->rec0;
+            const uint32_t es = Eseq[r], eq = Equal[r], eh = Ehdr[r], ep = Eplus[r];
+            L = Equal[r + 1] - eq; H = Ehdr[r + 1] - eh - 2; P = Eplus[r + 1] - ep - 2;
+            d_seq = p->a_off[S_SEQ] + (es - Eseq[r0]);
+            d_qual = p->a_off[S_QUAL] + (eq - Equal[r0]);
+            d_hdr = p->a_off[S_HDR] + (eh - Ehdr[r0]);
+            d_plus = p->a_off[S_PLUS] + (ep - Eplus[r0]);
+            // ---- length: u32 L (one coalesced store per lane); record prefixes: u16 H, u16 P (compress.go:509-519)
+            *(uint32_t *)(arena + p->a_off[S_LEN] + 4 * (r - r0)) = L;
+            uint8_t *dh = arena + d_hdr, *dp = arena + d_plus;
+            dh[0] = (uint8_t)H; dh[1] = (uint8_t)(H >> 8);
+            dp[0] = (uint8_t)P; dp[1] = (uint8_t)(P >> 8);
         }
-        // Piece-centric like the split: the reads that have N are cut into 16-base pieces, a lane finds the non-ACGT bases of
-        // one piece and writes their positions after those of the earlier pieces of the same read (wave scan of the
-        // per-piece counts minus its value at the read's first piece; a read that continues from the previous round takes
-        // the carried count).
-        const uint32_t limit = L < FQZ_MAX_SEQUENCE_LENGTH ? L : FQZ_MAX_SEQUENCE_LENGTH; // positions >= 65536 are not recorded
-        const uint32_t pn = NN ? (limit + 15) >> 4 : 0;
-        const uint32_t in_ = wave_incl_scan(pn);
-        const uint32_t Tn = (uint32_t)RL(in_, 63);
-        if (!Tn) continue;
-        const PieceMap pm = piece_map_make(pn, in_);
-        uint32_t carry = 0;
-        for (uint32_t base = 0; base < Tn; base += WAVE) {
-            const uint32_t p = base + lane;
-            const bool on = p < Tn;
-            uint32_t i, k;
-            piece_locate(pm, in_, pn, on ? p : 0, &i, &k);
-            const uint32_t lim_i = (uint32_t)__shfl((int)limit, (int)i, WAVE), src = (uint32_t)__shfl((int)s_seq, (int)i, WAVE);
-            const uint32_t dst = (uint32_t)__shfl((int)d_npos, (int)i, WAVE);
-            uint32_t bad16 = 0; // bit b: base 16 k + b is not one of ACGTacgt
-            if (on) {
-                uint32_t x[4];
-                load_piece(text, (size_t)src + 16 * k, n_text, x);
-                const uint32_t have = lim_i - 16 * k < 16 ? lim_i - 16 * k : 16;
+        const uint32_t pq = (L + 15) >> 4, ph = (H + 15) >> 4, pp = (P + 15) >> 4;
+        const uint32_t iq = wave_incl_scan(pq), ih = wave_incl_scan(ph), ip = wave_incl_scan(pp);
+        const PieceMap pm_iq = piece_map_make(pq, iq), pm_ih = piece_map_make(ph, ih), pm_ip = piece_map_make(pp, ip);
+        const uint32_t Tq = (uint32_t)RL(iq, 63), Th = (uint32_t)RL(ih, 63), Tp = (uint32_t)RL(ip, 63);
+
+        // ---- bases and qualities share the piece map (both lines of a record have L bytes): one pass, both loads in flight.
+        // bases: 16 bases -> 4 packed bytes (sequence.go:139-184); N counts go to E[nPos] (compress.go:477-488)
+        // quality: q'[0] = q[0]-off, q'[j] = q[j]-q[j-1], restarting per record (quality.go:53-103)
+        struct PieceJob { bool on; uint32_t i, k, have, dst, dstq, srcq, x[4], y[4], out, nn, beyond; };
+        auto fetch = [&](uint32_t p, PieceJob &J) { // every lane of the wave calls this
+            J.on = p < Tq;
+            piece_locate(pm_iq, iq, pq, J.on ? p : 0, &J.i, &J.k);
+            const uint32_t Li = (uint32_t)__shfl((int)L, (int)J.i, WAVE);
+            const uint32_t src = (uint32_t)__shfl((int)s_seq, (int)J.i, WAVE);
+            J.srcq = (uint32_t)__shfl((int)s_qual, (int)J.i, WAVE);
+            J.dst = (uint32_t)__shfl((int)d_seq, (int)J.i, WAVE);
+            J.dstq = (uint32_t)__shfl((int)d_qual, (int)J.i, WAVE);
+            J.have = Li - 16 * J.k < 16 ? Li - 16 * J.k : 16;
+#pragma unroll
+            for (int q = 0; q < 4; q++) J.x[q] = J.y[q] = 0;
+            if (J.on) {
+                load_piece(text, src + 16 * J.k, n_text, J.x);
+                load_piece(text, J.srcq + 16 * J.k, n_text, J.y);
+            }
+        };
+        // registers only (plus lane 0's one byte): x -> packed bases in `out`, y -> delta-coded qualities in y
+        auto compute = [&](PieceJob &J) {
+            // the byte before a quality piece is the last byte of the previous lane's piece (same read, k - 1); only lane 0
+            // has to fetch it from the text
+            const uint32_t left = (uint32_t)__shfl_up((int)(J.y[3] >> 24), 1, WAVE);
+            J.out = J.nn = J.beyond = 0;
+            if (J.on) {
+                const uint32_t have = J.have, k = J.k;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const uint32_t inv = ~acgt_mask(x[q]) & 0x80808080u;
-                    bad16 |= ((((inv >> 7) & 0x01010101u) * 0x01020408u) >> 24) << (4 * q);
+                    uint32_t v = J.x[q], in_read = 0x80808080u;
+                    if (have < 4u * q + 4) { // bytes past the read pack as 0
+                        const uint32_t hv = have > 4u * q ? have - 4u * q : 0;
+                        v = hv ? v & ((1u << (8 * hv)) - 1) : 0;
+                        in_read = hv ? in_read >> (8 * (4 - hv)) : 0;
+                    }
+                    const uint32_t vmask = acgt_mask(v);
+                    const uint32_t invalid = ~vmask & in_read;
+                    J.out |= pack4(v, vmask) << (8 * q);
+                    if (invalid) {
+                        const uint32_t b0 = 16 * k + 4 * q;
+                        if (b0 + 3 < FQZ_MAX_SEQUENCE_LENGTH) J.nn += __popc(invalid);
+                        else
+                            for (uint32_t z = 0; z < 4; z++)
+                                if (invalid & (0x80u << (8 * z))) { if (b0 + z < FQZ_MAX_SEQUENCE_LENGTH) J.nn++; else J.beyond = 1; }
+                    }
                 }
-                bad16 &= have >= 16 ? 0xFFFFu : ((1u << have) - 1);
+                uint32_t prev = k ? (lane ? left : text[J.srcq + 16 * k - 1]) : qoff;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const uint32_t yq = J.y[q]; J.y[q] = sub_bytes(yq, (yq << 8) | (prev & 0xFF)); prev = yq >> 24; }
             }
-            const uint32_t cntp = __popc(bad16);
-            const uint32_t incl = wave_incl_scan(cntp), excl = incl - cntp;
-            const uint32_t head_excl = (uint32_t)__shfl((int)excl, (int)(lane >= k ? lane - k : 0), WAVE);
-            uint32_t rank = lane >= k ? excl - head_excl : carry + excl;
+        };
+        // stores and atomics, after every load of the trip has been consumed: stores count in vmcnt like loads (gfx9), and a
+        // wait for the next round's loads behind them would wait for their acknowledgements too
+        auto commit = [&](PieceJob &J) {
+            if (J.on) {
+                const uint32_t have = J.have, k = J.k, out = J.out;
+                const uint32_t nb = (have + 3) >> 2;
+                uint8_t *o = arena + J.dst + 4 * k;
+                if (nb == 4) store_u32_unaligned(o, out);
+                else { // 1..3 packed bytes at the end of a read
+                    if (nb & 2) { uint16_t v = (uint16_t)out; __builtin_memcpy(o, &v, 2); }
+                    if (nb & 1) o[nb & 2] = (uint8_t)(out >> (8 * (nb & 2)));
+                }
+                if (J.beyond) report_error(info, g * 64 + J.i, 4, FQZ_E_LONG_N);
+                if (J.nn) atomicAdd(&Enpos[g * 64 + J.i], 2 * J.nn);
+                store_piece(arena + J.dstq + 16 * k, J.y, have);
+            }
+        };
+        // several rounds of 64 pieces per trip: 2 x SPLIT_ROUNDS loads per lane in flight before the first one is used
+        for (uint32_t base = 0; base < Tq; base += SPLIT_ROUNDS * WAVE) {
+            PieceJob J[SPLIT_ROUNDS];
+#pragma unroll
+            for (uint32_t u = 0; u < SPLIT_ROUNDS; u++)
+                if (base + u * WAVE < Tq) fetch(base + u * WAVE + lane, J[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < SPLIT_ROUNDS; u++)
+                if (base + u * WAVE < Tq) compute(J[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < SPLIT_ROUNDS; u++)
+                if (base + u * WAVE < Tq) commit(J[u]);
+        }
+        // ---- header and plus payloads (without '@' / '+'), after their u16 length
+        for (uint32_t base = 0; base < Th; base += WAVE) {
+            const uint32_t p = base + lane;
+            const bool on = p < Th;
+            uint32_t i, k;
+            piece_locate(pm_ih, ih, ph, on ? p : 0, &i, &k);
+            const uint32_t Hi = (uint32_t)__shfl((int)H, (int)i, WAVE), src = (uint32_t)__shfl((int)s_hdr, (int)i, WAVE);
+            const uint32_t dst = (uint32_t)__shfl((int)d_hdr, (int)i, WAVE);
             if (on) {
-                uint8_t *o = npos_arena + dst + 2;
-                uint32_t m2 = bad16;
-                while (m2) {
-                    const uint32_t bpos = 16 * k + (uint32_t)(__ffs(m2) - 1);
-                    m2 &= m2 - 1;
-                    o[2 * rank] = (uint8_t)bpos;
-                    o[2 * rank + 1] = (uint8_t)(bpos >> 8);
-                    rank++;
-                }
+                uint32_t x[4];
+                load_piece(text, src + 16 * k, n_text, x);
+                store_piece(arena + dst + 2 + 16 * k, x, Hi - 16 * k < 16 ? Hi - 16 * k : 16);
             }
-            const uint32_t before_l = lane >= k ? excl - head_excl : carry + excl;
-            carry = (uint32_t)RL(before_l + cntp, 63); // only read by lanes whose read started before the next round
+        }
+        for (uint32_t base = 0; base < Tp; base += WAVE) {
+            const uint32_t p = base + lane;
+            const bool on = p < Tp;
+            uint32_t i, k;
+            piece_locate(pm_ip, ip, pp, on ? p : 0, &i, &k);
+            const uint32_t Pi = (uint32_t)__shfl((int)P, (int)i, WAVE), src = (uint32_t)__shfl((int)s_plus, (int)i, WAVE);
+            const uint32_t dst = (uint32_t)__shfl((int)d_plus, (int)i, WAVE);
+            if (on) {
+                uint32_t x[4];
+                load_piece(text, src + 16 * k, n_text, x);
+                store_piece(arena + dst + 2 + 16 * k, x, Pi - 16 * k < 16 ? Pi - 16 * k : 16);
+            }
         }
     }
 }
-
 
 // ===========================================================================
 // K5/K6 entropy stage: one workgroup per 16 KiB chunk -> one zstd block
@@ -394,7 +842,7 @@ __global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPla
     if (g < group_cap) gmap[g] = make_uint4(chunk, p->a_off[s] + off, M | (last << 24) | ((uint32_t)s << 28), 0u);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_entropy(const EncInfo *info, const uint4 *gmap, const FsRegions reg,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_entropy(const EncInfo *info, const uint4 *gmap, const uint8_t *arena, const uint8_t *npos_arena,
                                                  uint8_t *slots, uint32_t *csize, int dbg_stop, unsigned long long *stamps)
 {
     __shared__ __attribute__((aligned(16))) EntropyLds S;
@@ -402,8 +850,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const uint4 gd = gmap[blockIdx.x];
     const uint32_t chunk = gd.x, M = gd.z & 0xFFFFFFu, last = (gd.z >> 24) & 1u, s = gd.z >> 28;
     if (stamps) { stamps += (size_t)chunk * 16; if (threadIdx.x == 0) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[15] = (unsigned long long)s; } }
-    const uint8_t *src = reg.p[s] + gd.y; // any alignment
+    const uint8_t *src = (s == S_NPOS ? npos_arena : arena) + gd.y; // 16-byte aligned
     entropy_encode_group(S, src, M, last, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
+}
+
+// N positions: u16 count + ascending u16 positions per record (compress.go:477-488, 507-512)
+__global__ __launch_bounds__(256) void k_npos_write(const uint8_t *text, uint32_t n_text, const uint32_t *ls, EncInfo *info, const uint32_t *E, uint32_t estride,
+                                                    const BlockPlan *plans, uint32_t rpb, uint8_t *npos_arena)
+{
+    const uint32_t n_rec = info->n_rec;
+    if (info->status) return;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    const uint32_t *Equal = E + (size_t)S_QUAL * estride, *Enpos = E + (size_t)S_NPOS * estride;
+    const uint32_t n_groups = (n_rec + 63) >> 6;
+    for (uint32_t g = wave; g < n_groups; g += nwaves) {
+        const uint32_t r = g * 64 + lane;
+        uint32_t s_seq = 0, L = 0, NN = 0, d_npos = 0;
+        if (r < n_rec) {
+            const BlockPlan *p = &plans[r / rpb];
+            uint32_t en = Enpos[r];
+            NN = (Enpos[r + 1] - en - 2) >> 1;
+            d_npos = p->a_off[S_NPOS] + (en - Enpos[p->rec0]);
+            uint8_t *dn = npos_arena + d_npos;
+            if (NN > 65535u) { report_error(info, r, 5, FQZ_E_FIELD_WRAP); NN = 0; }
+            dn[0] = (uint8_t)NN; dn[1] = (uint8_t)(NN >> 8);
+            if (NN) { s_seq = ls[4 * r + 1]; L = Equal[r + 1] - Equal[r]; }
+        }
+        // Piece-centric like k_split: the reads that have N are cut into 16-base pieces, a lane finds the non-ACGT bases of
+        // one piece and writes their positions after those of the earlier pieces of the same read (wave scan of the
+        // per-piece counts minus its value at the read's first piece; a read that continues from the previous round takes
+        // the carried count).  With N in most reads (5 % N) the old one-read-at-a-time loop cost as much as k_split.
+        const uint32_t limit = L < FQZ_MAX_SEQUENCE_LENGTH ? L : FQZ_MAX_SEQUENCE_LENGTH; // positions >= 65536 are not recorded
+        const uint32_t pn = NN ? (limit + 15) >> 4 : 0;
+        const uint32_t in_ = wave_incl_scan(pn);
+        const uint32_t Tn = (uint32_t)RL(in_, 63);
+        const PieceMap pm = piece_map_make(pn, in_);
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < Tn; base += WAVE) {
+            const uint32_t p = base + lane;
+            const bool on = p < Tn;
+            uint32_t i, k;
+            piece_locate(pm, in_, pn, on ? p : 0, &i, &k);
+            const uint32_t lim_i = (uint32_t)__shfl((int)limit, (int)i, WAVE), src = (uint32_t)__shfl((int)s_seq, (int)i, WAVE);
+            const uint32_t dst = (uint32_t)__shfl((int)d_npos, (int)i, WAVE);
+            uint32_t bad16 = 0; // bit b: base 16 k + b is not one of ACGTacgt
+            if (on) {
+                uint32_t x[4];
+                load_piece(text, (size_t)src + 16 * k, n_text, x);
+                const uint32_t have = lim_i - 16 * k < 16 ? lim_i - 16 * k : 16;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t inv = ~acgt_mask(x[q]) & 0x80808080u;
+                    bad16 |= ((((inv >> 7) & 0x01010101u) * 0x01020408u) >> 24) << (4 * q);
+                }
+                bad16 &= have >= 16 ? 0xFFFFu : ((1u << have) - 1);
+            }
+            const uint32_t cntp = __popc(bad16);
+            const uint32_t incl = wave_incl_scan(cntp), excl = incl - cntp;
+            const uint32_t head_excl = (uint32_t)__shfl((int)excl, (int)(lane >= k ? lane - k : 0), WAVE);
+            uint32_t rank = lane >= k ? excl - head_excl : carry + excl;
+            if (on) {
+                uint8_t *o = npos_arena + dst + 2;
+                uint32_t m2 = bad16;
+                while (m2) {
+                    const uint32_t bpos = 16 * k + (uint32_t)(__ffs(m2) - 1);
+                    m2 &= m2 - 1;
+                    o[2 * rank] = (uint8_t)bpos;
+                    o[2 * rank + 1] = (uint8_t)(bpos >> 8);
+                    rank++;
+                }
+            }
+            const uint32_t before_l = lane >= k ? excl - head_excl : carry + excl;
+            carry = (uint32_t)RL(before_l + cntp, 63); // only read by lanes whose read started before the next round
+        }
+    }
 }
 
 // ===========================================================================
@@ -528,15 +1048,6 @@ static unsigned long long *fqz_dbg_stamps(EncState &e)
     (void)hipMemset(e.stamps.p, 0, (size_t)e.chunk_cap * 16 * 8);
     return e.stamps.as<unsigned long long>();
 }
-int fqz_enc_get_fs_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_tiles, size_t *n_tiles)
-{
-    EncState &e = ctx->enc;
-    if (!e.fs_stamps.p || e.in_flight) return FQZ_E_ARG;
-    size_t n = e.n_tiles < max_tiles ? e.n_tiles : max_tiles;
-    HIP_TRY(hipMemcpy(out, e.fs_stamps.p, n * 64, hipMemcpyDeviceToHost));
-    *n_tiles = n;
-    return FQZ_OK;
-}
 int fqz_enc_get_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_chunks, size_t *n_chunks)
 {
     EncState &e = ctx->enc;
@@ -567,44 +1078,35 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     const uint32_t n = (uint32_t)n_bytes;
     const uint32_t final_batch = (flags & FQZ_BATCH_FINAL) ? 1u : 0u;
 
-    // ---- capacities (grown lazily; the record capacity assumes >= 32 bytes per record and is retried on overflow)
-    const bool small_tiles = e.small_tiles_left > 0; // (the text of the last batches had lines too short for the 32 KiB tiles' newline lists)
-    if (small_tiles) e.small_tiles_left--;
-    e.small_tiles_now = small_tiles;
-    const uint32_t tile_bytes = small_tiles ? 4096u : FS_TILE_BYTES;
-    e.n_tiles = (n + tile_bytes - 1) / tile_bytes;
-    uint32_t rec_cap = n / 32 + 1024;
-    if (e.rec_cap > rec_cap && e.n_bytes == n_bytes) rec_cap = e.rec_cap; // keep a grown capacity on retry
-    e.rec_cap = rec_cap;
+    // ---- capacities (grown lazily; the line capacity assumes >= 8 bytes per line and is retried on overflow)
+    e.n_tiles = (n + FQZ_TILE - 1) / FQZ_TILE;
+    uint32_t line_cap = n / 8 + 1024;
+    if (e.line_cap > line_cap && e.n_bytes == n_bytes) line_cap = e.line_cap; // keep a grown capacity on retry
+    e.line_cap = line_cap;
+    e.rec_cap = line_cap / 4 + 1;
     e.block_cap = e.rec_cap / rpb + 2;
-    FsCaps caps;
-    caps.cap[0] = (size_t)n / 8 + e.rec_cap + 4096;   // seq:  sum ceil(L/4)
-    caps.cap[1] = (size_t)n / 2 + 4096;               // qual: sum L
-    caps.cap[2] = (size_t)n + 4096;                   // headers: sum (2 + H) <= text
-    caps.cap[3] = (size_t)n + 4096;                   // plus
-    const size_t len_cap = 4ull * e.rec_cap + 4096;
-    e.npos_cap = (size_t)n + 2ull * e.rec_cap + 4096;
-    const size_t main_bytes = (size_t)n + 4ull * e.rec_cap + 4096;
-    const size_t main_cap = main_bytes / FQZ_CHUNK + 5ull * e.block_cap + 8;       // seq / qual / headers / plus / lengths chunks
+    e.arena_cap = (size_t)n + 4ull * e.rec_cap + 96ull * e.block_cap + 4096;
+    e.npos_cap = (size_t)n + 2ull * e.rec_cap + 16ull * e.block_cap + 4096;
+    const size_t main_cap = e.arena_cap / FQZ_CHUNK + 5ull * e.block_cap + 8;      // seq / qual / headers / plus / lengths chunks
     const size_t npos_chunk_cap = e.npos_cap / FQZ_CHUNK + 1ull * e.block_cap + 8; // nPos chunks
     const size_t chunk_cap = main_cap + npos_chunk_cap;
     if (chunk_cap > 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
     e.chunk_cap = (uint32_t)chunk_cap;
+    const uint32_t estride = e.rec_cap + 1;
 
     int rc;
     if ((rc = e.info.ensure(sizeof(EncInfo)))) return rc;
-    if ((rc = e.Enpos.ensure(4ull * (e.rec_cap + 8)))) return rc;
-    if ((rc = e.rec_seq.ensure(4ull * (e.rec_cap + 8)))) return rc;
-    if ((rc = e.rec_L.ensure(4ull * (e.rec_cap + 8)))) return rc;
-    if ((rc = e.bstart.ensure(sizeof(FsBStart) * ((size_t)e.block_cap + 2)))) return rc;
+    if ((rc = e.tile_cnt.ensure(4ull * (e.n_tiles + 2)))) return rc;
+    if ((rc = e.ls.ensure(4ull * (e.line_cap + 8)))) return rc;
+    if ((rc = e.lf.ensure(e.line_cap + 8))) return rc;
+    if ((rc = e.E.ensure(4ull * 5 * estride))) return rc;
     if ((rc = e.plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
-    if ((rc = e.reg[S_SEQ].ensure(caps.cap[0] + 64))) return rc;
-    if ((rc = e.reg[S_QUAL].ensure(caps.cap[1] + 64))) return rc;
-    if ((rc = e.reg[S_HDR].ensure(caps.cap[2] + 64))) return rc;
-    if ((rc = e.reg[S_PLUS].ensure(caps.cap[3] + 64))) return rc;
-    if ((rc = e.reg[S_LEN].ensure(len_cap + 64))) return rc;
-    if ((rc = e.reg[S_NPOS].ensure(e.npos_cap + 64))) return rc;
-    if ((rc = e.slots.ensure((size_t)e.chunk_cap * FQZ_SLOT))) return rc;
+    if ((rc = e.arena.ensure(e.arena_cap + 64))) return rc;
+    if ((rc = e.npos.ensure(e.npos_cap + 64))) return rc;
+    {
+        const size_t slot_bytes = (size_t)e.chunk_cap * FQZ_SLOT, local_bytes = 5ull * e.n_tiles * LL_CAP + 64; // (see k_line_local)
+        if ((rc = e.slots.ensure(slot_bytes > local_bytes ? slot_bytes : local_bytes))) return rc;
+    }
     if ((rc = e.csize.ensure(4ull * (2ull * e.chunk_cap + 4)))) return rc; // compressed sizes (scanned in place) | cinfo
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
     if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
@@ -613,57 +1115,56 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     e.d_text = d_text; e.n_bytes = n_bytes; e.rpb = rpb; e.flags = flags; e.d_out = d_out; e.out_cap = out_cap; e.stream = st;
 
     EncInfo *info = e.info.as<EncInfo>();
-    uint32_t *Enpos = e.Enpos.as<uint32_t>();
+    uint32_t *tile = e.tile_cnt.as<uint32_t>(), *ls = e.ls.as<uint32_t>(), *E = e.E.as<uint32_t>();
+    uint8_t *lf = e.lf.as<uint8_t>();
     uint32_t *csize = e.csize.as<uint32_t>();
     BlockPlan *plans = e.plans.as<BlockPlan>();
-    uint8_t *slots = e.slots.as<uint8_t>();
-    FsRegions reg;
-    for (int s = 0; s < FQZ_NS; s++) reg.p[s] = e.reg[s].as<uint8_t>();
+    uint8_t *arena = e.arena.as<uint8_t>(), *npos = e.npos.as<uint8_t>(), *slots = e.slots.as<uint8_t>();
 
-    // one zeroed buffer for every look-back state of the batch:
-    // [newline counts | stream sizes x 4 | newline counts of the detect pass | nPos scan | chunk scan | tickets]
-    const uint32_t zt_npos = e.rec_cap / SCAN_TILE + 2, zt_chunks = e.chunk_cap / SCAN_TILE + 2;
-    const uint32_t zwords = 6 * e.n_tiles + zt_npos + zt_chunks + 2;
+    // one zeroed buffer for every look-back state of the batch: [tile scan | nPos scan | chunk scan | record scan]
+    const uint32_t zt_tiles = e.n_tiles / SCAN_TILE + 2, zt_npos = e.rec_cap / SCAN_TILE + 2, zt_chunks = e.chunk_cap / SCAN_TILE + 2;
+    const uint32_t rs_tiles = e.rec_cap / RS_TILE + 1, zwords = zt_tiles + zt_npos + zt_chunks + 4 * rs_tiles + 1;
     if ((rc = e.zstate.ensure(8ull * zwords))) return rc;
-    unsigned long long *st1 = e.zstate.as<unsigned long long>(), *st2 = st1 + e.n_tiles, *st1d = st2 + 4ull * e.n_tiles;
-    unsigned long long *z_npos = st1d + e.n_tiles, *z_chunks = z_npos + zt_npos, *tickets = z_chunks + zt_chunks;
-    hipLaunchKernelGGL(k_init, dim3((zwords + 255) / 256 < 64 ? (zwords + 255) / 256 : 64), dim3(256), 0, st, info, qual_encoding, st1, zwords);
-    HIP_TRY(hipMemsetAsync(e.bstart.p, 0xFF, sizeof(FsBStart) * ((size_t)e.block_cap + 2), st));
-    FsArgs fa;
-    fa.text = d_text; fa.n = n; fa.n_tiles = e.n_tiles; fa.info = info; fa.st1 = st1; fa.st2 = st2; fa.ticket = (uint32_t *)tickets;
-    fa.reg = reg; fa.Enpos = Enpos; fa.rec_seq = e.rec_seq.as<uint32_t>(); fa.rec_L = e.rec_L.as<uint32_t>(); fa.bstart = e.bstart.as<FsBStart>();
-    fa.rec_cap = e.rec_cap; fa.block_cap = e.block_cap; fa.rpb = rpb; fa.final_batch = final_batch; fa.mode = 0;
+    unsigned long long *z_tiles = e.zstate.as<unsigned long long>(), *z_npos = z_tiles + zt_tiles, *z_chunks = z_npos + zt_npos, *rs_state = z_chunks + zt_chunks;
+    hipLaunchKernelGGL(k_init, dim3((zwords + 255) / 256 < 64 ? (zwords + 255) / 256 : 64), dim3(256), 0, st, info, qual_encoding, z_tiles, zwords);
+    const bool two_pass = e.two_pass_left > 0; // (the text of the last batches had lines too short for the single-pass index)
+    if (two_pass) e.two_pass_left--;
+    e.two_pass_now = two_pass;
+    if (e.n_tiles && !two_pass) {
+        // the tile-local line tables borrow the chunk slots, which nothing uses before k_entropy
+        uint32_t *lsl = (uint32_t *)slots;
+        uint8_t *lfl = slots + 4ull * e.n_tiles * LL_CAP;
+        PROF(ctx, st, "k_line_local", hipLaunchKernelGGL(k_line_local, dim3((e.n_tiles + 3) / 4), dim3(256), 0, st, d_text, n, e.n_tiles, ls, lf, lsl, lfl, tile, info));
+        if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, z_tiles))) return rc;
+        PROF(ctx, st, "k_line_gather", hipLaunchKernelGGL(k_line_gather, dim3((e.n_tiles + LG_TILES - 1) / LG_TILES), dim3(256), 0, st, tile, e.n_tiles, lsl, lfl, ls, lf, e.line_cap));
+    } else if (e.n_tiles) {
+        PROF(ctx, st, "k_count_nl", hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile));
+        if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, z_tiles))) return rc;
+        PROF(ctx, st, "k_line_starts", hipLaunchKernelGGL(k_line_starts, dim3((e.n_tiles + LI_SUB - 1) / LI_SUB), dim3(256), 0, st, d_text, n, e.n_tiles, tile, ls, lf, e.line_cap));
+    } else {
+        HIP_TRY(hipMemsetAsync(tile, 0, 8, st));
+        HIP_TRY(hipMemsetAsync(ls, 0, 8, st));
+        HIP_TRY(hipMemsetAsync(lf, 0, 8, st));
+    }
+    PROF(ctx, st, "k_setup_records", hipLaunchKernelGGL(k_setup_records, dim3(1), dim3(64), 0, st, info, tile, e.n_tiles, ls, e.line_cap, e.rec_cap, e.block_cap, rpb,
+                       final_batch, n));
     {
-        static int on = -1;
-        if (on < 0) { const char *v = getenv("FQZ_DBG_FS_STAMPS"); on = v ? atoi(v) : 0; }
-        fa.stamps = nullptr;
-        if (on && !e.fs_stamps.ensure((size_t)e.n_tiles * 64 + 64)) {
-            HIP_TRY(hipMemsetAsync(e.fs_stamps.p, 0, (size_t)e.n_tiles * 64, st));
-            fa.stamps = e.fs_stamps.as<unsigned long long>();
-        }
+        PROF(ctx, st, "k_record_scan", hipLaunchKernelGGL(k_record_scan, dim3(rs_tiles), dim3(256), 0, st, ls, lf, info, E, estride, final_batch, rs_state,
+                                                        (uint32_t *)(rs_state + 4ull * rs_tiles)));
     }
-    const uint32_t fs_grid = e.n_tiles < 2048u ? e.n_tiles : 2048u; // persistent workgroups: every one takes tile after tile by ticket
-    if (e.n_tiles) {
-        if (qual_encoding == FQZ_DETECT_ENCODING) { // encoder.DetectEncoding over block 0 (compress.go:146-154): a pass of its own, the offset is needed by the split
-            FsArgs fd = fa;
-            fd.mode = 1; fd.st1 = st1d; fd.ticket = (uint32_t *)(tickets + 1);
-            if (small_tiles) PROF(ctx, st, "k_detect", hipLaunchKernelGGL(k_fsplit<4096u>, dim3(fs_grid), dim3(FS_NT), 0, st, fd));
-            else PROF(ctx, st, "k_detect", hipLaunchKernelGGL(k_fsplit<FS_TILE_BYTES>, dim3(fs_grid), dim3(FS_NT), 0, st, fd));
-            hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
-        }
-        if (small_tiles) PROF(ctx, st, "k_fsplit", hipLaunchKernelGGL(k_fsplit<4096u>, dim3(fs_grid), dim3(FS_NT), 0, st, fa));
-        else PROF(ctx, st, "k_fsplit", hipLaunchKernelGGL(k_fsplit<FS_TILE_BYTES>, dim3(fs_grid), dim3(FS_NT), 0, st, fa));
+    if (qual_encoding == FQZ_DETECT_ENCODING) {
+        PROF(ctx, st, "k_detect", hipLaunchKernelGGL(k_detect, dim3(grid_for_waves(rpb < e.rec_cap ? rpb : e.rec_cap)), dim3(256), 0, st, d_text, ls, info, rpb));
+        hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
     }
-    PROF(ctx, st, "k_fplan", hipLaunchKernelGGL(k_fplan, dim3(1), dim3(256), 0, st, info, e.bstart.as<FsBStart>(), plans, n, rpb, final_batch, e.rec_cap, e.block_cap,
-                                               caps, (uint32_t)main_cap));
-    if ((rc = launch_scan(ctx, "scan_npos", st, Enpos, &info->n_rec, 0, e.rec_cap, z_npos))) return rc;
-    PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, st, info, Enpos, plans, e.chunk_cap));
-    PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, info, Enpos,
-                                                    e.rec_seq.as<uint32_t>(), e.rec_L.as<uint32_t>(), reg.p[S_NPOS]));
+    PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(256), 0, st, info, E, estride, plans, rpb, e.arena_cap, (uint32_t)main_cap));
+    PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
+    if ((rc = launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, z_npos))) return rc;
+    PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
+    PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, npos));
     const uint32_t group_cap = e.chunk_cap / FQZ_GROUP + FQZ_NS * e.block_cap + 8;
     if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
     PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap, csize + e.chunk_cap + 2));
-    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), reg, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, d_out));
@@ -692,15 +1193,15 @@ int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uin
         res->n_chunks = hi->n_chunks;
         for (int s = 0; s < FQZ_NS; s++) { res->stream_raw[s] = hi->stream_raw[s]; res->stream_comp[s] = hi->stream_comp[s]; }
     }
-    if (hi->status == FQZ_E_TOO_LARGE && hi->index_overflow && !e.small_tiles_now) {
-        // a 32 KiB tile with more newlines than its list in LDS holds: this batch is redone, and the next ones are done, with
-        // 4 KiB tiles (such inputs come in runs; after 16 launches the large tiles get another try)
-        e.small_tiles_left = 16;
+    if (hi->status == FQZ_E_TOO_LARGE && hi->index_overflow && !e.two_pass_now) {
+        // a tile with more lines than a tile-local slot holds: this batch is redone, and the next ones are done, with the
+        // two-pass index (such inputs come in runs; after 16 launches the single-pass index gets another try)
+        e.two_pass_left = 16;
         return FQZ_E_TOO_LARGE;
     }
-    if (hi->status == FQZ_E_TOO_LARGE && hi->n_rec_total > e.rec_cap) {
-        // more records than the optimistic capacity: remember the exact need so that a relaunch fits
-        e.rec_cap = hi->n_rec_total + 16;
+    if (hi->status == FQZ_E_TOO_LARGE && hi->n_lines > e.line_cap) {
+        // more lines than the optimistic capacity: remember the exact need so that a relaunch fits
+        e.line_cap = hi->n_lines + 16;
         return FQZ_E_TOO_LARGE;
     }
     if (hi->status) return hi->status;
@@ -729,7 +1230,7 @@ int fqz_enc_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_
         stream_len[s] = p.len[s];
         if (!streams || !streams[s]) continue;
         if (cap < p.len[s]) return FQZ_E_DST_SMALL;
-        const uint8_t *base = e.reg[s].as<uint8_t>() + p.a_off[s];
+        const uint8_t *base = (s == S_NPOS ? e.npos.as<uint8_t>() : e.arena.as<uint8_t>()) + p.a_off[s];
         if (p.len[s]) HIP_TRY(hipMemcpy(streams[s], base, p.len[s], hipMemcpyDeviceToHost));
     }
     return FQZ_OK;
@@ -769,7 +1270,7 @@ __global__ void k_single_layout(EncInfo *info, BlockPlan *plans, const uint32_t 
 int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, size_t *out_len, hipStream_t st)
 {
     EncState &e = ctx->enc;
-    if (e.in_flight || n >= 0x7FFFFFFFull) return FQZ_E_ARG;
+    if (e.in_flight || n >= 0x7FFFFFFFull || ((uintptr_t)d_src & 15)) return FQZ_E_ARG;
     uint32_t chunks = (uint32_t)((n + FQZ_CHUNK - 1) / FQZ_CHUNK);
     int rc;
     if ((rc = e.info.ensure(sizeof(EncInfo)))) return rc;
@@ -785,9 +1286,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     const uint32_t group_cap = chunks / FQZ_GROUP + 8;
     if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
     hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap, csize + chunks + 2);
-    FsRegions reg;
-    for (int s = 0; s < FQZ_NS; s++) reg.p[s] = const_cast<uint8_t *>(d_src);
-    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), reg, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
+    PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;
     hipLaunchKernelGGL(k_single_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_dst, cap);
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, csize + chunks + 2, d_dst));

@@ -268,7 +268,7 @@ __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc
 // ---------------------------------------------------------------------------------------------
 // One GROUP of up to FQZ_GROUP consecutive 16 KiB chunks of a stream -> one zstd block per chunk, all sharing ONE
 // Huffman table built from the histogram of the whole group (the first Compressed block carries the tree, the
-// others are treeless).  src is global memory (any alignment) holding the M group bytes; chunk k goes to
+// others are treeless).  src is 16-byte aligned global memory holding the M group bytes; chunk k goes to
 // slot0 + k * FQZ_SLOT and its size to csize0[k].  All 256 threads call this; they return together.
 //
 // The kernel is bound by the LDS pipeline (histogram atomics, code-table lookups, bit packing, the table build), so:
@@ -304,8 +304,8 @@ __device__ __forceinline__ void load_chunk_syms(EntropyLds &S, const uint8_t *sr
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
     C.nstreams = m >= 256 ? 4 : 1;
     if (m == FQZ_CHUNK) {
-        const uint8_t *p = src + 4096 * wave + 64 * lane; // (any alignment: a block's part of a stream starts where the last one ended)
-        const uint4 a = load_u128_unaligned(p), b = load_u128_unaligned(p + 16), c = load_u128_unaligned(p + 32), d = load_u128_unaligned(p + 48);
+        const uint4 *p = (const uint4 *)(src + 4096 * wave + 64 * lane);
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
         C.sym[0] = a.x; C.sym[1] = a.y; C.sym[2] = a.z; C.sym[3] = a.w; C.sym[4] = b.x; C.sym[5] = b.y; C.sym[6] = b.z; C.sym[7] = b.w;
         C.sym[8] = c.x; C.sym[9] = c.y; C.sym[10] = c.z; C.sym[11] = c.w; C.sym[12] = d.x; C.sym[13] = d.y; C.sym[14] = d.z; C.sym[15] = d.w;
         C.cnt = 64;
@@ -327,7 +327,7 @@ __device__ __forceinline__ void load_chunk_syms(EntropyLds &S, const uint8_t *sr
         const uint32_t off = (t + 256 * q) * 16;
         const uint32_t have = off < m ? (m - off < 16 ? m - off : 16) : 0;
         v[q] = make_uint4(0, 0, 0, 0);
-        if (have == 16) v[q] = load_u128_unaligned(src + off);
+        if (have == 16) v[q] = *(const uint4 *)(src + off);
         else if (have) {
             uint32_t w[4] = {0, 0, 0, 0};
             for (uint32_t k = 0; k < have; k++) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
@@ -731,7 +731,7 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
             const uint32_t bh = lastblk | (0u << 1) | (mk << 3);
             if (t == 0) { slot[0] = (uint8_t)bh; slot[1] = (uint8_t)(bh >> 8); slot[2] = (uint8_t)(bh >> 16); }
             for (uint32_t off = t * 16; off < mk; off += 256 * 16) {
-                if (off + 16 <= mk) store_u128_unaligned(slot + 3 + off, load_u128_unaligned(csrc + off));
+                if (off + 16 <= mk) store_u128_unaligned(slot + 3 + off, *(const uint4 *)(csrc + off));
                 else
                     for (uint32_t q = off; q < mk; q++) slot[3 + q] = csrc[q];
             }

@@ -31,9 +31,8 @@ struct EncInfo {
     uint32_t n_groups;      // chunk groups (k_group_map)
     uint32_t arena_used;    // bytes of the main arena in use
     uint32_t npos_used;
-    uint32_t index_overflow; // a text tile holds more newlines than its list in LDS (k_fsplit): redo with 4 KiB tiles
-    uint32_t detect_done_tile; // DetectEncoding pass: first tile that starts beyond block 0
-    unsigned long long tot[4]; // bytes of the seq / qual / headers / plus streams of every complete record of the batch
+    uint32_t index_overflow; // a 4 KiB tile holds more lines than its tile-local slot (k_line_local)
+    uint32_t pad0;
     unsigned long long error_key; // (record << 8 | check order << 4 | code index), min wins
     unsigned long long out_len;
     unsigned long long stream_raw[FQZ_NS];

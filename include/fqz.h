@@ -179,8 +179,6 @@ int fqz_debug_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], siz
 
 /* Diagnostic hook (FQZ_DBG_STAMPS=1 in the environment): per-chunk s_memtime stamps of the entropy kernel's phases. */
 int fqz_debug_get_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_chunks, size_t *n_chunks);
-/* Diagnostic hook (FQZ_DBG_FS_STAMPS=1): 8 s_memtime stamps per text tile of the fused parse + split kernel. */
-int fqz_debug_get_fs_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_tiles, size_t *n_tiles);
 
 /* ---- internal/encoder primitive mirrors (GPU-executed, host buffers) ----- */
 /* encoder.PackBases / AppendPackedBases (sequence.go:58,139): packed gets

@@ -10,7 +10,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); k = d['kernel_ms']; dk = d['decode_kernel_ms']
-        print('$v', 'enc_ms', d['ms_per_step'], 'dec_MBps', d['decode_MBps'], 'ok', d['roundtrip_bit_exact'], {n: k[n] for n in ('k_entropy', 'k_fsplit', 'k_fplan', 'k_npos_write', 'k_compact') if n in k}, {n: dk[n] for n in ('k_dec_assemble', 'k_dec_huf', 'k_dec_frames') if n in dk})
+        print('$v', 'enc_ms', d['ms_per_step'], 'dec_MBps', d['decode_MBps'], 'ok', d['roundtrip_bit_exact'], {n: k[n] for n in ('k_entropy', 'k_split', 'k_line_local', 'k_compact') if n in k}, {n: dk[n] for n in ('k_dec_assemble', 'k_dec_huf', 'k_dec_frames') if n in dk})
 "
   done
 done
