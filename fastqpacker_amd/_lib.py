@@ -82,6 +82,7 @@ SIGNATURES = {
     "fqz_write_block_header": (C.c_int, [C.POINTER(BlockHeader), C.c_uint8, _u8p]),
     "fqz_read_block_header": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint8, C.POINTER(BlockHeader)]),
     "fqz_encode_bound": (C.c_size_t, [C.c_size_t]),
+    "fqz_encode_bound_blocks": (C.c_size_t, [C.c_size_t, C.c_uint32]),
     "fqz_encode_block": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "fqz_decode_block": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint8, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "fqz_decode_block_size": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint8, C.POINTER(C.c_size_t)]),

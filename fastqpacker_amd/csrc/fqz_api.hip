@@ -56,6 +56,7 @@ extern "C" const char *fqz_strerror(int code)
     case FQZ_E_ARG: return "invalid argument";
     case FQZ_E_TOO_LARGE: return "batch too large for one device pass";
     case FQZ_E_IO: return "I/O error";
+    case FQZ_E_CHECKSUM: return "decompressing stream: CRC check failed";
     default: return "unknown error";
     }
 }
@@ -95,11 +96,11 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     EncState &e = c->enc;
-    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.stamps, &e.lf, &e.zstate, &e.scan_state, &e.gmap};
+    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.stamps, &e.lf, &e.zstate, &e.scan_state, &e.gmap, &e.xmap};
     for (DevBuf *b : eb) b->release();
     e.h_info.release(); e.h_plans.release();
     DecState &d = c->dec;
-    DevBuf *db[] = {&d.info, &d.blocks, &d.chunks, &d.streams, &d.rec, &d.partials, &d.tables, &d.lz_scratch};
+    DevBuf *db[] = {&d.info, &d.blocks, &d.chunks, &d.frames, &d.streams, &d.rec, &d.partials, &d.tables, &d.lz_scratch};
     for (DevBuf *b : db) b->release();
     d.h_info.release(); d.h_blocks.release();
     if (d.side) { (void)hipStreamSynchronize(d.side); (void)hipStreamDestroy(d.side); (void)hipEventDestroy(d.ev_fork); (void)hipEventDestroy(d.ev_join); }
@@ -178,15 +179,21 @@ extern "C" int fqz_read_block_header(const uint8_t *in, size_t n, uint8_t versio
 extern "C" size_t fqz_entropy_bound(size_t n)
 {
     if (!n) return 0;
-    return 10 + n + 3 * ((n + FQZ_CHUNK - 1) / FQZ_CHUNK);
+    // FQZ-H2 payload: index frame (24 + 3 per zstd block), per 64 KiB group a frame header and a checksum, per block a header
+    const size_t chunks = (n + FQZ_CHUNK - 1) / FQZ_CHUNK, groups = (chunks + FQZ_GROUP - 1) / FQZ_GROUP;
+    return 24 + 3 * chunks + 11 * groups + n + 3 * chunks;
 }
 
-extern "C" size_t fqz_encode_bound(size_t n_bytes)
+extern "C" size_t fqz_encode_bound_blocks(size_t n_bytes, uint32_t rpb)
 {
-    // pre-entropy bytes <= 2*text + small per-record terms (each record has >= 4 text bytes),
-    // every chunk stored raw, plus block and frame headers
-    return 2 * n_bytes + (n_bytes / 1024 + 64) * 128 + 4096;
+    // pre-entropy bytes <= 2*text + small per-record terms (each record has >= 6 text bytes), every chunk stored raw,
+    // per zstd block 6 bytes (header + index entry), per 64 KiB group 11; per block of records a 36-byte header and six
+    // payloads with a 24-byte index, a short last group and a short last chunk each
+    if (!rpb) rpb = FQZ_DEFAULT_BLOCK_SIZE;
+    const size_t blocks = n_bytes / 6 / rpb + 2;
+    return 2 * n_bytes + (n_bytes / 1024 + 64) * 128 + blocks * (36 + 6 * (24 + 11 + 6)) + 4096;
 }
+extern "C" size_t fqz_encode_bound(size_t n_bytes) { return fqz_encode_bound_blocks(n_bytes, FQZ_DEFAULT_BLOCK_SIZE); }
 
 // ===========================================================================
 // device-resident batches
@@ -272,7 +279,7 @@ static int encode_staged(fqz_ctx *ctx, const uint8_t *fastq, size_t n, uint32_t 
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = stage_in(ctx, fastq, n);
     if (rc) return rc;
-    size_t cap = fqz_encode_bound(n);
+    size_t cap = fqz_encode_bound_blocks(n, rpb);
     if ((rc = ctx->d_out.ensure(cap + 64))) return rc;
     size_t max_blocks = n / 4 / (rpb ? rpb : 1) + 2;
     if (offs) { offs->assign(max_blocks, 0); lens->assign(max_blocks, 0); }
@@ -658,7 +665,7 @@ extern "C" int fqz_delta_decode(fqz_ctx *ctx, uint8_t *q, size_t n) { return pri
 // ===========================================================================
 // entropy stage alone
 // ===========================================================================
-int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, size_t *out_len, hipStream_t st);
+int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, size_t *payload_off, size_t *out_len, hipStream_t st);
 int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, size_t *out_len, hipStream_t st);
 
 extern "C" int fqz_entropy_encode(fqz_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len)
@@ -669,13 +676,13 @@ extern "C" int fqz_entropy_encode(fqz_ctx *ctx, const uint8_t *src, size_t n, ui
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = stage_in(ctx, src, n);
     if (rc) return rc;
-    size_t bound = fqz_entropy_bound(n);
+    size_t bound = fqz_entropy_bound(n) + 64;
     if ((rc = ctx->d_out.ensure(bound + 64))) return rc;
-    size_t got = 0;
-    rc = fqz_enc_entropy_only(ctx, ctx->d_in.as<uint8_t>(), n, ctx->d_out.as<uint8_t>(), bound, &got, ctx->stream);
+    size_t got = 0, off = 0;
+    rc = fqz_enc_entropy_only(ctx, ctx->d_in.as<uint8_t>(), n, ctx->d_out.as<uint8_t>(), bound, &off, &got, ctx->stream);
     if (rc) return rc;
     if (got > cap) return FQZ_E_DST_SMALL;
-    HIP_TRY(hipMemcpy(dst, ctx->d_out.p, got, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dst, ctx->d_out.as<uint8_t>() + off, got, hipMemcpyDeviceToHost));
     *out_len = got;
     return FQZ_OK;
 }

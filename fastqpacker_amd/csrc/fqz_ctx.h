@@ -78,6 +78,7 @@ struct EncState {
     DevBuf zstate;    // look-back states and tickets of the batch's scans (zeroed by k_init)
     DevBuf scan_state; // look-back states of k_scan + its ticket
     DevBuf gmap;      // chunk-group descriptors (k_group_map)
+    DevBuf xmap;      // descriptors of every group (frame) for the content checksums | xsum[chunk_cap]
     DevBuf plans;     // BlockPlan[block_cap]
     DevBuf arena;     // seq/qual/hdr/plus/len pre-entropy streams
     DevBuf npos;      // nPos pre-entropy streams
@@ -98,7 +99,7 @@ struct DecState {
     hipStream_t side = nullptr;            // bases + qualities are entropy-decoded here while the record walks run on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool in_flight = false;
-    DevBuf info, blocks, chunks, streams, rec, partials, tables, lz_scratch;
+    DevBuf info, blocks, chunks, frames, streams, rec, partials, tables, lz_scratch;
     PinnedBuf h_info, h_blocks;
     uint32_t n_blocks = 0;
     // arguments of the launch in flight (a decode that guessed the frame layout wrong is relaunched from finish)

@@ -11,6 +11,7 @@
 // with LZ sequences (files written by the stock encoder) are reported as FQZ_E_ENTROPY.
 #include "fqz_ctx.h"
 #include "fqz_device.h"
+#include "fqz_xxh.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -29,6 +30,16 @@ struct DecBlock {
     uint32_t walk_mode[3];          // 1 = offsets already written by k_dec_walk0
     uint32_t walk_cand[3];          // entry offsets k_dec_walk1 precomputes per tile (64 / 128 / 256, by average record length)
     uint32_t lz[FQZ_NS];            // 0, or 1 + scratch slot: the payload is a foreign frame with LZ sequences (k_dec_lz)
+    uint32_t indexed[FQZ_NS];       // the payload starts with our index frame (FQZ-H2): its zstd blocks are located without a walk
+    uint32_t n_frames[FQZ_NS];      // zstd frames of the payload (content checksums are verified per frame)
+    uint32_t frame_base[FQZ_NS];    // first entry of the payload in the frame table
+};
+
+struct DecFrame {
+    uint32_t dst_off;   // arena offset of the frame's content
+    uint32_t len;       // content bytes
+    uint32_t ck_off;    // offset in d_in of the 4-byte Content_Checksum (0: the frame carries none)
+    uint32_t stream;    // S_SEQ .. S_LEN (the verification launches take a stream mask)
 };
 
 struct DecChunk {
@@ -118,6 +129,22 @@ __device__ int frame_header(const uint8_t *p, uint32_t n, uint32_t *hdr, long lo
     return 0;
 }
 
+// zstd skippable frame (RFC 8878 3.1.2): magic 0x184D2A5? + u32 size; decoders skip it
+__device__ __forceinline__ bool skippable_magic(const uint8_t *p) { return (p[0] & 0xF0) == 0x50 && p[1] == 0x2A && p[2] == 0x4D && p[3] == 0x18; }
+// FQZ-H2 index in front of a payload: 'FQZI', version 1, stream, pre-entropy length, zstd block count, 3 bytes per block
+#define H2_IDX_HDR 24u
+__device__ __forceinline__ bool h2_index(const uint8_t *p, uint32_t n, uint32_t *raw, uint32_t *nch)
+{
+    if (n < H2_IDX_HDR || !skippable_magic(p) || p[0] != 0x50) return false;
+    if (!(p[8] == 'F' && p[9] == 'Q' && p[10] == 'Z' && p[11] == 'I' && p[12] == 1)) return false;
+    const uint32_t sz = rd32(p + 4), r = rd32(p + 16), c = rd32(p + 20);
+    if (r == 0 || r > 0x7FFFFFF0u || c != (r + FQZ_CHUNK - 1) / FQZ_CHUNK) return false;
+    if (sz != H2_IDX_HDR - 8 + 3ull * c || 8ull + sz > n) return false;
+    *raw = r;
+    *nch = c;
+    return true;
+}
+
 // regenerated size of a Compressed block = its literals' Regenerated_Size (there are no sequences)
 __device__ int literals_regen(const uint8_t *p, uint32_t n, uint32_t *regen)
 {
@@ -150,13 +177,23 @@ __global__ __launch_bounds__(64) void k_dec_fhdr(const uint8_t *in, DecInfo *inf
     DecBlock *b = &blocks[id / FQZ_NS];
     const int s = id % FQZ_NS;
     const uint32_t n = b->pay_len[s];
-    if (!n) { b->raw_len[s] = 0; b->n_chunks[s] = 0; return; }
+    b->indexed[s] = 0;
+    if (!n) { b->raw_len[s] = 0; b->n_chunks[s] = 0; b->n_frames[s] = 0; return; }
+    uint32_t raw, nch;
+    if (h2_index(in + b->pay_off[s], n, &raw, &nch)) { // our own payload: sizes and block places come from its index (k_dec_index)
+        b->raw_len[s] = raw;
+        b->n_chunks[s] = nch;
+        b->n_frames[s] = (nch + FQZ_GROUP - 1) / FQZ_GROUP;
+        b->indexed[s] = 1;
+        return;
+    }
     uint32_t hdr;
     long long fcs;
     int ck;
     if (frame_header(in + b->pay_off[s], n, &hdr, &fcs, &ck) < 0 || fcs < 0 || fcs > 0x7FFFFFF0ll) { b->raw_len[s] = FQZ_SPEC_UNKNOWN; return; }
     b->raw_len[s] = (uint32_t)fcs;
     b->n_chunks[s] = fcs ? (uint32_t)((fcs + FQZ_CHUNK - 1) / FQZ_CHUNK) : 1u;
+    b->n_frames[s] = 1;
 }
 
 // One workgroup per (block, stream).  The chain of zstd block headers is sequential (every header tells where the
@@ -207,12 +244,13 @@ __device__ __forceinline__ void frame_win_tail(uint8_t *buf, const uint8_t *in, 
 // walker state, kept in LDS between windows so that inside the walking wave every value is wave-uniform (SGPRs)
 struct FrameWalk {
     uint32_t pos, nch, dst, in_frame, ck, state; // state: 0 = go on, 1 = done, 2 = failed
+    uint32_t nfr, fstart;                         // frames completed, arena offset of the current frame's content
     uint32_t fcs_lo, fcs_hi, has_fcs, lz;
     uint32_t tree_off, tree_len; // last Huffman tree description seen in the frame (for treeless blocks)
     uint32_t frame_regen_lo, frame_regen_hi, total_lo, total_hi;
 };
 
-__global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint32_t in_bytes, DecInfo *info, DecBlock *blocks, DecChunk *chunks, int pass)
+__global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint32_t in_bytes, DecInfo *info, DecBlock *blocks, DecChunk *chunks, DecFrame *frames, int pass)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[2][FRAME_BUF];
     __shared__ FrameWalk W;
@@ -222,9 +260,12 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
     DecBlock *b = &blocks[id / FQZ_NS];
     const int s = id % FQZ_NS;
     if (pass == 1 && b->lz[s]) return; // a foreign frame: decoded as a whole by k_dec_lz
+    if (pass == 2 && b->indexed[s]) return; // our own payload with its index: k_dec_index places the blocks without a walk
 #define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x))) // wave-uniform values live in SGPRs: the walk runs on the scalar unit
     const uint32_t p0 = UNI(b->pay_off[s]), n = UNI(b->pay_len[s]); // the payload is in[p0, p0 + n); `in` is 16-byte aligned
     DecChunk *out = pass ? chunks + UNI(b->chunk_base[s]) : nullptr;
+    DecFrame *fout = pass && frames ? frames + UNI(b->frame_base[s]) : nullptr;
+    const uint32_t nfr_expected = UNI(b->n_frames[s]);
     const uint32_t n_expected = UNI(b->n_chunks[s]);
     if (t == 0) {
         FrameWalk z;
@@ -258,6 +299,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
         } else {
             // wave 0, every lane with the same values: the chain of block headers is walked with scalar instructions
             uint32_t pos = UNI(W.pos), nch = UNI(W.nch), dst = UNI(W.dst), in_frame = UNI(W.in_frame), ck = UNI(W.ck), st = 0;
+            uint32_t nfr = UNI(W.nfr), fstart = UNI(W.fstart);
             uint32_t has_fcs = UNI(W.has_fcs), lz = 0, tree_off = UNI(W.tree_off), tree_len = UNI(W.tree_len);
             unsigned long long fcs = ((unsigned long long)UNI(W.fcs_hi) << 32) | UNI(W.fcs_lo);
             unsigned long long frame_regen = ((unsigned long long)UNI(W.frame_regen_hi) << 32) | UNI(W.frame_regen_lo);
@@ -270,6 +312,14 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                 const uint8_t *q = wbuf + (rel - wlo);
                 if (!in_frame) {
                     if (pos >= n) { st = 1; break; }
+                    if (n - pos >= 8 && UNI(skippable_magic(q))) { // a skippable frame (our index, or anybody's metadata): not content
+                        uint32_t ssz;
+                        __builtin_memcpy(&ssz, q + 4, 4);
+                        ssz = UNI(ssz);
+                        if (ssz > n - pos - 8) { st = 2; break; }
+                        pos += 8 + ssz;
+                        continue;
+                    }
                     uint32_t hdr;
                     long long f64;
                     int ck0;
@@ -281,6 +331,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                     frame_regen = 0;
                     in_frame = 1;
                     tree_len = 0;
+                    fstart = dst;
                     continue;
                 }
                 // block header (3 bytes) and the literals header behind it (<= 5 bytes) in one LDS round trip; everything
@@ -337,14 +388,22 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                 pos = cpos + csize;
                 frame_regen += regen;
                 if (last) {
-                    if (ck) { if (n - pos < 4) { st = 2; break; } pos += 4; }
+                    if (ck && n - pos < 4) { st = 2; break; }
                     if (has_fcs && fcs != frame_regen) { st = 2; break; }
+                    if (fout && (pass == 1 || nfr < nfr_expected) && t == 0) {
+                        DecFrame f;
+                        f.dst_off = fstart; f.len = (uint32_t)frame_regen; f.ck_off = ck ? p0 + pos : 0u; f.stream = (uint32_t)s;
+                        fout[nfr] = f;
+                    }
+                    nfr++;
+                    if (ck) pos += 4;
                     regen_total += frame_regen;
                     in_frame = 0;
                 }
             }
             if (t == 0) {
                 W.pos = pos; W.nch = nch; W.dst = dst; W.in_frame = in_frame; W.ck = ck; W.state = st; W.has_fcs = has_fcs; W.lz = lz; W.tree_off = tree_off; W.tree_len = tree_len;
+                W.nfr = nfr; W.fstart = fstart;
                 W.fcs_lo = (uint32_t)fcs; W.fcs_hi = (uint32_t)(fcs >> 32);
                 W.frame_regen_lo = (uint32_t)frame_regen; W.frame_regen_hi = (uint32_t)(frame_regen >> 32);
                 W.total_lo = (uint32_t)regen_total; W.total_hi = (uint32_t)(regen_total >> 32);
@@ -361,11 +420,11 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
     if (t == 0) {
         const unsigned long long regen_total = ((unsigned long long)W.total_hi << 32) | W.total_lo;
         if (W.state == 3) { dec_fail(info, FQZ_DEC_RETRY_GENERAL); return; }
-        if (W.lz) { b->raw_len[s] = W.fcs_lo; b->n_chunks[s] = 0; b->lz[s] = 1; return; }
+        if (W.lz) { b->raw_len[s] = W.fcs_lo; b->n_chunks[s] = 0; b->n_frames[s] = 0; b->lz[s] = 1; return; }
         if (W.state == 2 || W.in_frame) { dec_fail(info, FQZ_E_ENTROPY); return; }
         if (regen_total > 0x7FFFFFFFull) { dec_fail(info, FQZ_E_TOO_LARGE); return; }
-        if (!pass) { b->raw_len[s] = (uint32_t)regen_total; b->n_chunks[s] = W.nch; }
-        if (pass == 2 && (W.nch != n_expected || regen_total != b->raw_len[s])) dec_fail(info, FQZ_DEC_RETRY_GENERAL);
+        if (!pass) { b->raw_len[s] = (uint32_t)regen_total; b->n_chunks[s] = W.nch; b->n_frames[s] = W.nfr; }
+        if (pass == 2 && (W.nch != n_expected || regen_total != b->raw_len[s] || W.nfr != nfr_expected)) dec_fail(info, FQZ_DEC_RETRY_GENERAL);
     }
 }
 
@@ -570,8 +629,120 @@ __global__ __launch_bounds__(64) void k_dec_lz(const uint8_t *in, DecInfo *info,
     const int s = id % FQZ_NS;
     const uint32_t slot = LZU(b->lz[s]);
     if (!slot) return;
-    if (lz_decode_frame(L, in + LZU(b->pay_off[s]), LZU(b->pay_len[s]), arena + LZU(b->a_off[s]), LZU(b->raw_len[s]), scratch + (size_t)(slot - 1) * LZ_SCRATCH) < 0)
-        dec_fail(info, FQZ_E_ENTROPY);
+    const int r = lz_decode_frame(L, in + LZU(b->pay_off[s]), LZU(b->pay_len[s]), arena + LZU(b->a_off[s]), LZU(b->raw_len[s]), scratch + (size_t)(slot - 1) * LZ_SCRATCH);
+    if (r < 0) dec_fail(info, r == -2 ? FQZ_E_CHECKSUM : FQZ_E_ENTROPY);
+}
+
+// ---------------------------------------------------------------------------
+// FQZ-H2 payloads: the index in front of the payload gives the size of every zstd block, so the block table is built
+// in parallel instead of by a walk along the chain of block headers.  One workgroup per (block, stream): a scan of the
+// sizes places every block; a thread per block then checks that a block of that size really starts there, reads its
+// type and finds the Huffman tree a treeless block refers to (an earlier block of its group).  Anything that does not
+// add up sends the batch down the general path (the index is a hint, never trusted).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dec_index(const uint8_t *in, DecInfo *info, const DecBlock *blocks, DecChunk *chunks, DecFrame *frames)
+{
+    __shared__ uint32_t sh[4];
+    const uint32_t id = blockIdx.x, t = threadIdx.x;
+    if (id >= info->n_blocks * FQZ_NS || info->status) return;
+    const DecBlock *b = &blocks[id / FQZ_NS];
+    const int s = id % FQZ_NS;
+    if (!b->indexed[s]) return;
+    const uint32_t p0 = b->pay_off[s], n = b->pay_len[s], raw = b->raw_len[s], nch = b->n_chunks[s];
+    const uint8_t *idx = in + p0 + H2_IDX_HDR;
+    DecChunk *out = chunks + b->chunk_base[s];
+    DecFrame *fout = frames + b->frame_base[s];
+    const uint32_t body0 = p0 + H2_IDX_HDR + 3 * nch; // first byte behind the index
+    uint32_t carry = 0;
+    bool bad = false;
+    for (uint32_t c0 = 0; c0 < nch; c0 += 256) {
+        const uint32_t c = c0 + t;
+        const uint32_t sz = c < nch ? rd24(idx + 3 * c) : 0u;
+        uint32_t tot;
+        const uint32_t before = carry + block_excl_scan_256(sz, sh, &tot);
+        carry += tot;
+        if (c < nch) {
+            const uint32_t g = c / FQZ_GROUP, cg = c % FQZ_GROUP;
+            const uint32_t M = raw - g * FQZ_GROUP * FQZ_CHUNK < FQZ_GROUP * FQZ_CHUNK ? raw - g * FQZ_GROUP * FQZ_CHUNK : FQZ_GROUP * FQZ_CHUNK;
+            const uint32_t fh = M < 256u ? 6u : 7u;
+            const unsigned long long pos64 = (unsigned long long)body0 + 11ull * g + fh + before; // the block header
+            const uint32_t mk = raw - c * FQZ_CHUNK < FQZ_CHUNK ? raw - c * FQZ_CHUNK : FQZ_CHUNK;
+            const bool last_in_group = cg == FQZ_GROUP - 1 || c + 1 == nch;
+            if (sz < 4 || pos64 + sz + (last_in_group ? 4 : 0) > (unsigned long long)p0 + n) bad = true;
+            else {
+                const uint32_t pos = (uint32_t)pos64;
+                const uint8_t *q = in + pos;
+                const uint32_t bh = rd24(q), last = bh & 1, type = (bh >> 1) & 3, bs = bh >> 3;
+                const uint32_t csize = type == 1 ? 1u : bs;
+                DecChunk d;
+                d.src_off = pos + 3; d.csize = csize; d.dst_off = b->a_off[s] + c * FQZ_CHUNK; d.regen = mk; d.btype = type;
+                d.tree_off = 0; d.tree_len = 0; d.stream = (uint32_t)s;
+                if (type == 3 || 3 + csize != sz || last != (last_in_group ? 1u : 0u)) bad = true;
+                else if (type != 2) { if (bs != mk) bad = true; }
+                else {
+                    // Compressed block: literals only (Number_of_Sequences = 0), regenerating exactly the chunk
+                    const uint32_t lh = q[3] | ((uint32_t)q[4] << 8) | ((uint32_t)q[5] << 16) | ((uint32_t)q[6] << 24);
+                    const uint32_t lt2 = lh & 3, fmt = (lh >> 2) & 3, l4 = lh >> 4;
+                    const uint32_t r_plain = fmt == 1 ? (l4 & 0xFFFu) : (fmt == 3 ? (l4 & 0xFFFFFu) : ((lh & 0xFFu) >> 3));
+                    const uint32_t n_plain = fmt == 1 ? 2u : (fmt == 3 ? 3u : 1u);
+                    const uint32_t r_huf = fmt <= 1 ? (l4 & 0x3FFu) : (fmt == 2 ? (l4 & 0x3FFFu) : (l4 & 0x3FFFFu));
+                    const uint32_t n_huf = fmt <= 1 ? 3u : (fmt == 2 ? 4u : 5u);
+                    const uint32_t need = lt2 <= 1 ? n_plain : n_huf;
+                    const uint32_t c_huf = fmt <= 1 ? ((lh >> 14) & 0x3FFu) : (fmt == 2 ? ((lh >> 18) & 0x3FFFu) : (((lh >> 22) | ((uint32_t)q[7] << 10)) & 0x3FFFFu));
+                    const uint32_t lit_total = need + (lt2 == 0 ? r_plain : (lt2 == 1 ? 1u : c_huf));
+                    const uint32_t regen = lt2 <= 1 ? r_plain : r_huf;
+                    if (bs < need || lit_total + 1 != bs || regen != mk) bad = true;
+                    else if (lt2 == 3) { // treeless: the tree travels with an earlier Compressed block of the group
+                        uint32_t back = 0; // bytes from that block's header to this one's
+                        bool found = false;
+                        for (uint32_t j = 1; j <= cg && !found; j++) {
+                            back += rd24(idx + 3 * (c - j));
+                            if (back > pos - body0) { bad = true; break; }
+                            const uint8_t *qj = in + pos - back;
+                            const uint32_t bhj = rd24(qj);
+                            if (((bhj >> 1) & 3) != 2) continue;
+                            const uint32_t lhj = qj[3] | ((uint32_t)qj[4] << 8) | ((uint32_t)qj[5] << 16) | ((uint32_t)qj[6] << 24);
+                            if ((lhj & 3) != 2) continue;
+                            const uint32_t fj = (lhj >> 2) & 3;
+                            d.tree_off = pos - back + 3 + (fj <= 1 ? 3u : (fj == 2 ? 4u : 5u));
+                            d.tree_len = fj <= 1 ? ((lhj >> 14) & 0x3FFu) : (fj == 2 ? ((lhj >> 18) & 0x3FFFu) : (((lhj >> 22) | ((uint32_t)qj[7] << 10)) & 0x3FFFFu));
+                            found = true;
+                        }
+                        if (!found) bad = true;
+                    }
+                }
+                if (cg == 0 && !bad) { // the group's frame header sits right in front of its first block
+                    const uint8_t *f = q - fh;
+                    const bool ok = f[0] == 0x28 && f[1] == 0xB5 && f[2] == 0x2F && f[3] == 0xFD &&
+                                    (M < 256u ? (f[4] == 0x24 && f[5] == M) : (f[4] == 0x64 && (uint32_t)(f[5] | (f[6] << 8)) == M - 256u));
+                    if (!ok) bad = true;
+                }
+                if (last_in_group && !bad) {
+                    DecFrame fr;
+                    fr.dst_off = b->a_off[s] + g * FQZ_GROUP * FQZ_CHUNK; fr.len = M; fr.ck_off = pos + sz; fr.stream = (uint32_t)s;
+                    fout[g] = fr;
+                    if (c + 1 == nch && pos + sz + 4 != p0 + n) bad = true; // the payload ends with the last checksum
+                }
+                out[c] = d;
+            }
+        }
+        __syncthreads();
+    }
+    if (bad) dec_fail(info, FQZ_DEC_RETRY_GENERAL);
+}
+
+// Content checksums: four lanes per frame, 16 frames per wave; a mismatch fails the decode (the reference's decoder
+// verifies them too: zstd.Decoder defaults, compress.go:120-122).
+__global__ __launch_bounds__(64) void k_dec_xxh(const uint8_t *in, DecInfo *info, const DecFrame *frames, uint32_t n_frames, const uint8_t *arena, uint32_t stream_mask)
+{
+    if (info->status) return;
+    const uint32_t lane = threadIdx.x, f = blockIdx.x * 16 + (lane >> 2);
+    DecFrame fr;
+    fr.dst_off = fr.len = fr.ck_off = fr.stream = 0;
+    if (f < n_frames) fr = frames[f];
+    const bool on = f < n_frames && fr.ck_off && ((stream_mask >> fr.stream) & 1u);
+    const unsigned long long h = xxh64_quad(arena + fr.dst_off, on ? fr.len : 0u, lane);
+    if (on && (lane & 3) == 0 && (uint32_t)h != rd32(in + fr.ck_off)) dec_fail(info, FQZ_E_CHECKSUM);
 }
 
 // ---------------------------------------------------------------------------
@@ -1511,7 +1682,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     HIP_TRY(hipMemsetAsync(blocks, 0, sizeof(DecBlock) * (size_t)nb, st));
     PROF(ctx, st, "k_dec_blocks", hipLaunchKernelGGL(k_dec_blocks, dim3(1), dim3(64), 0, st, d_in, n, (uint32_t)version, info, blocks, nb));
     uint32_t fgrid = nb * FQZ_NS; // one wave per (block, stream)
-    if (general) PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, (DecChunk *)nullptr, 0));
+    if (general) PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, (DecChunk *)nullptr, (DecFrame *)nullptr, 0));
     else PROF(ctx, st, "k_dec_fhdr", hipLaunchKernelGGL(k_dec_fhdr, dim3((fgrid + 63) / 64), dim3(64), 0, st, d_in, info, blocks));
     HIP_TRY(hipMemcpyAsync(hi, info, sizeof(DecInfo), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(d.h_blocks.p, blocks, sizeof(DecBlock) * (size_t)nb, hipMemcpyDeviceToHost, st));
@@ -1525,7 +1696,8 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     }
     // ---- layout on the host: arena offsets, chunk bases, output bound
     DecBlock *hb = d.h_blocks.as<DecBlock>();
-    unsigned long long arena = 0, chunks = 0, out_bound = 0, tiles = 0, n_lz = 0;
+    unsigned long long arena = 0, chunks = 0, out_bound = 0, tiles = 0, n_lz = 0, nframes = 0;
+    bool any_indexed = false;
     for (int s = 0; s < FQZ_NS; s++) { hi->stream_raw[s] = 0; hi->stream_comp[s] = 0; }
     for (uint32_t b = 0; b < nb; b++) {
         for (int s = 0; s < FQZ_NS; s++) {
@@ -1533,6 +1705,10 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             arena += ((unsigned long long)hb[b].raw_len[s] + 15 + 16) & ~15ull; // +16: tile loads read whole uint4
             hb[b].chunk_base[s] = (uint32_t)chunks;
             chunks += hb[b].n_chunks[s];
+            hb[b].frame_base[s] = (uint32_t)nframes;
+            nframes += hb[b].n_frames[s];
+            if (general) hb[b].indexed[s] = 0; // the general path walks every payload, index or not
+            any_indexed |= hb[b].indexed[s] != 0;
             if (hb[b].lz[s]) hb[b].lz[s] = (uint32_t)++n_lz; // 1 + scratch slot
             hi->stream_raw[s] += hb[b].raw_len[s];
             hi->stream_comp[s] += hb[b].pay_len[s];
@@ -1554,7 +1730,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         if (2ull * nr > hb[b].raw_len[S_HDR]) return FQZ_E_TRUNC_HEADER;
         if (hb[b].raw_len[S_PLUS] && 2ull * nr > hb[b].raw_len[S_PLUS]) return FQZ_E_TRUNC_PLUS;
     }
-    if (arena > 0xFFFFFFF0ull || chunks > 0x7FFFFFFFull || out_bound > 0xFFFFFFF0ull || tiles > 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
+    if (arena > 0xFFFFFFF0ull || chunks > 0x7FFFFFFFull || out_bound > 0xFFFFFFF0ull || tiles > 0x7FFFFFFFull || nframes > 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
     const uint32_t n_tiles = (uint32_t)tiles;
     if (!d_out) { // host-buffer entry points: decode into the context's staging buffer
         if ((rc = ctx->d_out.ensure((size_t)out_bound + 64))) return rc;
@@ -1567,6 +1743,9 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     if ((rc = d.streams.ensure((size_t)arena + 64))) return rc;
     if (n_lz && (rc = d.lz_scratch.ensure((size_t)n_lz * LZ_SCRATCH))) return rc;
     if ((rc = d.chunks.ensure(sizeof(DecChunk) * ((size_t)n_chunks + 1)))) return rc;
+    const uint32_t n_frames = (uint32_t)nframes;
+    if ((rc = d.frames.ensure(sizeof(DecFrame) * ((size_t)n_frames + 1)))) return rc;
+    DecFrame *dfr = d.frames.as<DecFrame>();
     if ((rc = d.rec.ensure(4ull * (3ull * ostride + 3ull * cstride) + 64))) return rc;
     uint32_t pmax = n_rec / DSCAN_TILE + 2;
     if ((rc = d.partials.ensure(4ull * 3 * pmax + 24ull * ((size_t)nb + 1)))) return rc;
@@ -1582,7 +1761,8 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     hi->n_chunks = n_chunks;
     HIP_TRY(hipMemcpyAsync(&info->n_chunks, &hi->n_chunks, 4, hipMemcpyHostToDevice, st));
     // ---- bulk kernels
-    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, dch, general ? 1 : 2));
+    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, dch, dfr, general ? 1 : 2));
+    if (any_indexed) PROF(ctx, st, "k_dec_index", hipLaunchKernelGGL(k_dec_index, dim3(fgrid), dim3(256), 0, st, d_in, info, blocks, dch, dfr));
     // The record walks and the size scans below need only the header / plus / nPos / lengths streams, the text assembly
     // at the end needs the bases and qualities too.  The latter are 3/4 of the entropy decode and the walks leave the
     // chip almost empty, so the two run side by side: bases + qualities on the context's side stream, joined before
@@ -1602,6 +1782,10 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, st, d_in, info, dch, darena, early));
         PROF(ctx, d.side, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, d.side, d_in, info, dch, darena, dbg, late));
         PROF(ctx, d.side, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, d.side, d_in, info, dch, darena, late));
+        if (n_frames) { // content checksums of the decoded frames: beside the walks / on the side stream, like the decodes they check
+            PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + 15) / 16), dim3(64), 0, st, d_in, info, dfr, n_frames, darena, early));
+            PROF(ctx, d.side, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + 15) / 16), dim3(64), 0, d.side, d_in, info, dfr, n_frames, darena, late));
+        }
         HIP_TRY(hipEventRecord(d.ev_join, d.side));
         forked = true;
     }
@@ -1688,7 +1872,7 @@ int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     *hi = z;
     HIP_TRY(hipMemcpyAsync(info, hi, sizeof z, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(blocks, hb, sizeof *hb, hipMemcpyHostToDevice, st));
-    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, (DecChunk *)nullptr, 0));
+    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, (DecChunk *)nullptr, (DecFrame *)nullptr, 0));
     HIP_TRY(hipMemcpyAsync(hi, info, sizeof z, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hb, blocks, sizeof *hb, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1709,14 +1893,17 @@ int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
         return FQZ_OK;
     }
     if ((rc = d.chunks.ensure(sizeof(DecChunk) * ((size_t)nch + 1)))) return rc;
-    for (int s = 1; s < FQZ_NS; s++) hb->chunk_base[s] = nch;
+    const uint32_t nfr = hb->n_frames[S_SEQ];
+    if ((rc = d.frames.ensure(sizeof(DecFrame) * ((size_t)nfr + 1)))) return rc;
+    for (int s = 1; s < FQZ_NS; s++) { hb->chunk_base[s] = nch; hb->frame_base[s] = nfr; }
     hi->n_chunks = nch;
     HIP_TRY(hipMemcpyAsync(blocks, hb, sizeof *hb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(&info->n_chunks, &hi->n_chunks, 4, hipMemcpyHostToDevice, st));
-    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, d.chunks.as<DecChunk>(), 1));
+    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, d.chunks.as<DecChunk>(), d.frames.as<DecFrame>(), 1));
     if (nch) {
         PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((nch + HG - 1) / HG), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0, 0x3Fu));
         PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(nch), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0x3Fu));
+        if (nfr) PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((nfr + 15) / 16), dim3(64), 0, st, d_src, info, d.frames.as<DecFrame>(), nfr, d_dst, 0x3Fu));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hi, info, sizeof z, hipMemcpyDeviceToHost, st));

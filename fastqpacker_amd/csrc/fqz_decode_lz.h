@@ -304,6 +304,13 @@ __device__ int lz_decode_frame(LzLds &L, const uint8_t *in, uint32_t n, uint8_t 
         }
         if (last) break;
     }
-    if (ck) { if (n - pos < 4) return -1; pos += 4; } // the content checksum is not verified
+    if (ck) { // Content_Checksum: low 32 bits of XXH64 over the frame's content (four lanes hash; a 15 MB stock frame is a long serial chain)
+        if (n - pos < 4 || out != raw) return -1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        const unsigned long long h = xxh64_quad(dst, lane < 4 ? raw : 0u, lane);
+        const uint32_t want = in[pos] | ((uint32_t)in[pos + 1] << 8) | ((uint32_t)in[pos + 2] << 16) | ((uint32_t)in[pos + 3] << 24);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)h) != want) return -2;
+        pos += 4;
+    }
     return (pos == n && out == raw) ? 0 : -1;
 }

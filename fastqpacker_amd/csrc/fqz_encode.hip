@@ -14,6 +14,7 @@
 #include "fqz_ctx.h"
 #include "fqz_device.h"
 #include "fqz_entropy_dev.h"
+#include "fqz_xxh.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -822,10 +823,18 @@ __device__ __forceinline__ void locate_chunk(const EncInfo *info, const BlockPla
     *cidx = chunk - p->chunk_base[s];
 }
 
-// groups of up to FQZ_GROUP consecutive chunks of one stream share a Huffman table: one thread per chunk finds the
-// group leaders and appends a descriptor {first chunk id, arena offset, bytes | last << 24 | stream << 28, 0}
+// FQZ-H2 payload geometry of a stream of len bytes (nch chunks, ng groups): [24-byte index header | 3 bytes per chunk |
+// per group: frame header (6 bytes when the group holds < 256 bytes, else 7), its zstd blocks, 4-byte checksum]
+__device__ __forceinline__ uint32_t h2_idx_len(uint32_t nch) { return 24u + 3u * nch; }
+__device__ __forceinline__ uint32_t h2_group_bytes(uint32_t len, uint32_t g) { const uint32_t off = g * FQZ_GROUP * FQZ_CHUNK; return len - off < FQZ_GROUP * FQZ_CHUNK ? len - off : FQZ_GROUP * FQZ_CHUNK; }
+__device__ __forceinline__ uint32_t h2_frame_hdr(uint32_t M) { return M < 256u ? 6u : 7u; }
+
+// Groups of up to FQZ_GROUP consecutive chunks of one stream form one zstd frame and share a Huffman table.  One thread
+// per chunk: group leaders append a descriptor {first chunk id, arena offset, bytes | stream << 28, 0} to xmap (every
+// group: its content is hashed by k_xxh) and, unless the stream is the 2-bit packed bases, to gmap (k_entropy).  The bases
+// are Raw blocks by definition: their "compressed" size is known here and k_compact copies them straight from the arena.
 // cinfo[chunk] = block | stream << 24, for k_compact (which would otherwise repeat the search, one dependent load after another)
-__global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPlan *plans, uint4 *gmap, uint32_t group_cap, uint32_t *cinfo)
+__global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPlan *plans, uint4 *gmap, uint4 *xmap, uint32_t group_cap, uint32_t *cinfo, uint32_t *csize)
 {
     const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
     if (chunk >= info->n_chunks) return;
@@ -833,13 +842,17 @@ __global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPla
     int s;
     locate_chunk(info, plans, chunk, &b, &s, &c);
     cinfo[chunk] = b | ((uint32_t)s << 24);
-    if (c % FQZ_GROUP) return;
     const BlockPlan *p = &plans[b];
     const uint32_t off = c * FQZ_CHUNK;
+    if (s == S_SEQ) csize[chunk] = 3u + (p->len[s] - off < FQZ_CHUNK ? p->len[s] - off : FQZ_CHUNK); // Raw block: header + bytes
+    if (c % FQZ_GROUP) return;
     const uint32_t M = p->len[s] - off < FQZ_GROUP * FQZ_CHUNK ? p->len[s] - off : FQZ_GROUP * FQZ_CHUNK;
-    const uint32_t last = off + M == p->len[s];
-    const uint32_t g = atomicAdd(&info->n_groups, 1u); // any order: groups are independent
-    if (g < group_cap) gmap[g] = make_uint4(chunk, p->a_off[s] + off, M | (last << 24) | ((uint32_t)s << 28), 0u);
+    const uint4 d = make_uint4(chunk, p->a_off[s] + off, M | ((uint32_t)s << 28), 0u);
+    const uint32_t x = atomicAdd(&info->n_xgroups, 1u); // any order: groups are independent
+    if (x < group_cap) xmap[x] = d;
+    if (s == S_SEQ) return;
+    const uint32_t g = atomicAdd(&info->n_groups, 1u);
+    if (g < group_cap) gmap[g] = d;
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_entropy(const EncInfo *info, const uint4 *gmap, const uint8_t *arena, const uint8_t *npos_arena,
@@ -848,10 +861,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     __shared__ __attribute__((aligned(16))) EntropyLds S;
     if (blockIdx.x >= info->n_groups) return;
     const uint4 gd = gmap[blockIdx.x];
-    const uint32_t chunk = gd.x, M = gd.z & 0xFFFFFFu, last = (gd.z >> 24) & 1u, s = gd.z >> 28;
+    const uint32_t chunk = gd.x, M = gd.z & 0xFFFFFFu, s = gd.z >> 28;
     if (stamps) { stamps += (size_t)chunk * 16; if (threadIdx.x == 0) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[15] = (unsigned long long)s; } }
     const uint8_t *src = (s == S_NPOS ? npos_arena : arena) + gd.y; // 16-byte aligned
-    entropy_encode_group(S, src, M, last, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
+    entropy_encode_group(S, src, M, 0u, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
+}
+
+// Content checksum of every frame (= group): four lanes per group, 16 groups per wave (fqz_xxh.h).  xsum[first chunk] = low 32 bits.
+__global__ __launch_bounds__(64) void k_xxh(const EncInfo *info, const uint4 *xmap, const uint8_t *arena, const uint8_t *npos_arena, uint32_t *xsum)
+{
+    const uint32_t lane = threadIdx.x, g = blockIdx.x * 16 + (lane >> 2);
+    const bool on = g < info->n_xgroups;
+    uint4 gd = make_uint4(0, 0, 0, 0);
+    if (on) gd = xmap[g];
+    const uint32_t s = gd.z >> 28;
+    const unsigned long long h = xxh64_quad((s == S_NPOS ? npos_arena : arena) + gd.y, on ? gd.z & 0xFFFFFFu : 0u, lane);
+    if (on && (lane & 3) == 0) xsum[gd.x] = (uint32_t)h;
 }
 
 // N positions: u16 count + ascending u16 positions per record (compress.go:477-488, 507-512)
@@ -953,8 +978,10 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
         if (p) {
             size = 36;
             for (int s = 0; s < FQZ_NS; s++) {
-                uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
-                flen[s] = nch ? 10 + (cpre[p->chunk_base[s] + nch] - cpre[p->chunk_base[s]]) : 0;
+                const uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK, ng = (nch + FQZ_GROUP - 1) / FQZ_GROUP;
+                // index frame + per group (frame header + checksum) + the zstd blocks
+                flen[s] = nch ? h2_idx_len(nch) + 11u * (ng - 1) + h2_frame_hdr(h2_group_bytes(p->len[s], ng - 1)) + 4u +
+                                    (cpre[p->chunk_base[s] + nch] - cpre[p->chunk_base[s]]) : 0;
                 size += flen[s];
             }
         }
@@ -996,20 +1023,27 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
         put_le32(h + 32, p->orig_seq);
         for (int s = 0; s < FQZ_NS; s++) {
             if (!p->frame_len[s]) continue;
+            // the index: a zstd skippable frame in front of the payload's frames (k_compact fills in the block sizes)
+            const uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
             uint8_t *f = out + p->frame_off[s];
-            f[0] = 0x28; f[1] = 0xB5; f[2] = 0x2F; f[3] = 0xFD; // zstd magic
-            f[4] = 0x80;                                        // FCS 4 bytes, windowed, no checksum
-            f[5] = 0x38;                                        // window 128 KiB
-            put_le32(f + 6, p->len[s]);
+            put_le32(f, 0x184D2A50u);
+            put_le32(f + 4, h2_idx_len(nch) - 8);
+            f[8] = 'F'; f[9] = 'Q'; f[10] = 'Z'; f[11] = 'I';
+            f[12] = 1; f[13] = (uint8_t)s; f[14] = 0; f[15] = 0;
+            put_le32(f + 16, p->len[s]);
+            put_le32(f + 20, nch);
         }
     }
 }
 
-// One workgroup per chunk: slot (16-byte aligned) -> its place in the frame (any alignment).  The destination comes from
-// three dependent loads (cinfo -> plan -> scanned sizes), uniform across the workgroup, so they go through the scalar unit;
-// the body is copied in 16-byte rows aligned to the destination.
+// One workgroup per chunk: its zstd block -> its place in its frame (any alignment), plus what frames the block: the
+// chunk's entry in the payload's index, the frame header in front of a group's first block, the content checksum behind
+// its last.  The block comes from the chunk's slot (16-byte aligned), or - 2-bit packed bases: Raw blocks by definition -
+// straight from the arena behind a 3-byte block header made here.  The destination comes from three dependent loads
+// (cinfo -> plan -> scanned sizes), uniform across the workgroup, so they go through the scalar unit; the body is copied
+// in 16-byte rows aligned to the destination.
 __global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const BlockPlan *plans, const uint8_t *slots, const uint32_t *cpre,
-                                                 const uint32_t *cinfo, uint8_t *out)
+                                                 const uint32_t *cinfo, const uint32_t *xsum, const uint8_t *arena, uint8_t *out, uint32_t seq_stream)
 {
     const uint32_t chunk = blockIdx.x;
     if (info->status || chunk >= info->n_chunks) return;
@@ -1017,9 +1051,32 @@ __global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const Bloc
     const uint32_t ci = cinfo[chunk], c0 = cpre[chunk], c1 = cpre[chunk + 1];
     const BlockPlan *p = &plans[ci & 0xFFFFFFu];
     const uint32_t s = ci >> 24;
-    uint8_t *dst = out + p->frame_off[s] + 10 + (c0 - cpre[p->chunk_base[s]]);
-    const uint32_t n = c1 - c0;
+    const uint32_t base = p->chunk_base[s], c = chunk - base, len = p->len[s];
+    const uint32_t nch = (len + FQZ_CHUNK - 1) / FQZ_CHUNK, g = c / FQZ_GROUP;
+    const uint32_t M = h2_group_bytes(len, g), fh = h2_frame_hdr(M);
+    uint8_t *const pay = out + p->frame_off[s];
+    uint8_t *dst = pay + h2_idx_len(nch) + 11u * g + fh + (c0 - cpre[base]);
+    uint32_t n = c1 - c0;
+    const bool first_in_group = c % FQZ_GROUP == 0, last_in_group = c % FQZ_GROUP == FQZ_GROUP - 1 || c + 1 == nch;
+    if (t == 0) {
+        uint8_t *e = pay + 24 + 3 * c; // index entry: size of this zstd block, header included
+        e[0] = (uint8_t)n; e[1] = (uint8_t)(n >> 8); e[2] = (uint8_t)(n >> 16);
+        if (first_in_group) { // Frame_Header: magic, descriptor (single segment, checksum, content size field), content size
+            uint8_t *f = dst - fh;
+            f[0] = 0x28; f[1] = 0xB5; f[2] = 0x2F; f[3] = 0xFD;
+            if (M < 256u) { f[4] = 0x24; f[5] = (uint8_t)M; }
+            else { f[4] = 0x64; f[5] = (uint8_t)(M - 256u); f[6] = (uint8_t)((M - 256u) >> 8); }
+        }
+        if (last_in_group) put_le32(dst + n, xsum[base + g * FQZ_GROUP]); // Content_Checksum: low 32 bits of XXH64 over the group
+    }
     const uint8_t *src = slots + (size_t)chunk * FQZ_SLOT;
+    if (s == seq_stream) { // Raw block: 3-byte header, then the chunk's bytes as they lie in the arena
+        const uint32_t mk = n - 3, bh = (last_in_group ? 1u : 0u) | (0u << 1) | (mk << 3);
+        if (t == 0) { dst[0] = (uint8_t)bh; dst[1] = (uint8_t)(bh >> 8); dst[2] = (uint8_t)(bh >> 16); }
+        src = arena + p->a_off[s] + (size_t)c * FQZ_CHUNK;
+        dst += 3;
+        n = mk;
+    }
     uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
     if (head > n) head = n;
     if (t < head) dst[t] = src[t];
@@ -1163,11 +1220,15 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, npos));
     const uint32_t group_cap = e.chunk_cap / FQZ_GROUP + FQZ_NS * e.block_cap + 8;
     if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
-    PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap, csize + e.chunk_cap + 2));
+    if ((rc = e.xmap.ensure(16ull * group_cap + 4ull * (e.chunk_cap + 8)))) return rc;
+    uint32_t *xsum = (uint32_t *)(e.xmap.as<uint4>() + group_cap);
+    PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), e.xmap.as<uint4>(), group_cap,
+                                                    csize + e.chunk_cap + 2, csize));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
+    PROF(ctx, st, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + 15) / 16), dim3(64), 0, st, info, e.xmap.as<uint4>(), arena, npos, xsum));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
-    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, d_out));
+    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, xsum, arena, d_out, (uint32_t)S_SEQ));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
     e.in_flight = true;
@@ -1245,32 +1306,21 @@ __global__ void k_single_plan(EncInfo *info, BlockPlan *plans, uint32_t n)
     BlockPlan p;
     memset(&p, 0, sizeof p);
     p.nrec = 1;
-    p.len[S_SEQ] = n;
+    p.len[S_QUAL] = n; // a stream of no particular kind is coded like the quality stream (S_SEQ would be stored Raw)
     uint32_t chunks = (n + FQZ_CHUNK - 1) / FQZ_CHUNK;
-    for (int s = 1; s < FQZ_NS; s++) p.chunk_base[s] = chunks;
+    for (int s = S_QUAL + 1; s < FQZ_NS; s++) p.chunk_base[s] = chunks;
     plans[0] = p;
     info->n_blocks = 1;
     info->n_chunks = chunks;
     info->n_main = chunks;
 }
 
-__global__ void k_single_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap)
-{
-    if (threadIdx.x || blockIdx.x) return;
-    BlockPlan *p = &plans[0];
-    uint32_t flen = 10 + cpre[info->n_chunks];
-    p->frame_off[S_SEQ] = 0;
-    p->frame_len[S_SEQ] = flen;
-    info->out_len = flen;
-    if (flen > out_cap) { info->status = FQZ_E_DST_SMALL; return; }
-    out[0] = 0x28; out[1] = 0xB5; out[2] = 0x2F; out[3] = 0xFD; out[4] = 0x80; out[5] = 0x38;
-    put_le32(out + 6, p->len[S_SEQ]);
-}
-
-int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, size_t *out_len, hipStream_t st)
+// one stream -> its FQZ-H2 payload.  The pipeline of a one-block batch whose only stream is `d_src` runs into d_dst; the
+// payload lies behind the 36-byte block header (*payload_off).
+int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *d_dst, size_t cap, size_t *payload_off, size_t *out_len, hipStream_t st)
 {
     EncState &e = ctx->enc;
-    if (e.in_flight || n >= 0x7FFFFFFFull || ((uintptr_t)d_src & 15)) return FQZ_E_ARG;
+    if (e.in_flight || n >= 0x7FFFFFFFull || ((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 15)) return FQZ_E_ARG;
     uint32_t chunks = (uint32_t)((n + FQZ_CHUNK - 1) / FQZ_CHUNK);
     int rc;
     if ((rc = e.info.ensure(sizeof(EncInfo)))) return rc;
@@ -1278,6 +1328,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     if ((rc = e.slots.ensure((size_t)(chunks + 1) * FQZ_SLOT))) return rc;
     if ((rc = e.csize.ensure(4ull * (2ull * chunks + 4)))) return rc;
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
+    if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * 2))) return rc;
     EncInfo *info = e.info.as<EncInfo>();
     BlockPlan *plans = e.plans.as<BlockPlan>();
     uint32_t *csize = e.csize.as<uint32_t>();
@@ -1285,16 +1336,22 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     hipLaunchKernelGGL(k_single_plan, dim3(1), dim3(64), 0, st, info, plans, (uint32_t)n);
     const uint32_t group_cap = chunks / FQZ_GROUP + 8;
     if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
-    hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), group_cap, csize + chunks + 2);
+    if ((rc = e.xmap.ensure(16ull * group_cap + 4ull * (chunks + 8)))) return rc;
+    uint32_t *xsum = (uint32_t *)(e.xmap.as<uint4>() + group_cap);
+    hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), e.xmap.as<uint4>(), group_cap, csize + chunks + 2, csize);
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
+    PROF(ctx, st, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + 15) / 16), dim3(64), 0, st, info, e.xmap.as<uint4>(), d_src, d_src, xsum));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;
-    hipLaunchKernelGGL(k_single_layout, dim3(1), dim3(64), 0, st, info, plans, csize, d_dst, cap);
-    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, csize + chunks + 2, d_dst));
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_dst, cap);
+    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks ? chunks : 1), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, csize + chunks + 2, xsum, d_src, d_dst, (uint32_t)S_SEQ));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(e.h_plans.p, plans, sizeof(BlockPlan), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const EncInfo *hi = e.h_info.as<EncInfo>();
     if (hi->status) return hi->status;
-    *out_len = hi->out_len;
+    const BlockPlan *hp = e.h_plans.as<BlockPlan>();
+    *payload_off = hp->frame_off[S_QUAL];
+    *out_len = hp->frame_len[S_QUAL];
     return FQZ_OK;
 }

@@ -344,9 +344,12 @@ __device__ __forceinline__ void load_chunk_syms(EntropyLds &S, const uint8_t *sr
     __syncthreads(); // the staged copy may be overwritten
 }
 
-__device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const uint32_t M, const uint32_t last, uint8_t *slot0, uint32_t *csize0,
+// Every group is a zstd frame of its own (FQZ-H2): its last chunk carries the Last_Block bit.  force_raw: the 2-bit packed
+// bases are Raw blocks by definition - no histogram, no table, no bit counting.
+__device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const uint32_t M, const uint32_t force_raw, uint8_t *slot0, uint32_t *csize0,
                                      const int dbg_stop = 0, unsigned long long *stamps = nullptr)
 {
+    const uint32_t last = 1;
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const uint32_t nchunk = (M + FQZ_CHUNK - 1) / FQZ_CHUNK;
     const uint32_t m = M; // the table-build code below speaks of "m": the byte count the histogram covers
@@ -357,7 +360,7 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
     S.ctab[t] = 0;
     uint32_t same_mask = 0; // bit k: chunk k is one repeated byte
 #pragma clang loop unroll(disable)
-    for (uint32_t k = 0; k < nchunk; k++) {
+    for (uint32_t k = 0; k < (force_raw ? 0u : nchunk); k++) {
         const uint32_t mk = M - k * FQZ_CHUNK < FQZ_CHUNK ? M - k * FQZ_CHUNK : FQZ_CHUNK;
         const uint8_t *csrc = src + (size_t)k * FQZ_CHUNK;
         ChunkSyms C;
@@ -398,7 +401,8 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
     __syncthreads();
     const uint32_t n_active = S.misc[8] + S.misc[9] + S.misc[10] + S.misc[11];
     uint32_t mode = 2;
-    {
+    if (force_raw) mode = 0;
+    else {
         unsigned long long sq = (unsigned long long)S.misc[16] + S.misc[17] + S.misc[18] + S.misc[19];
         if (n_active == 1) mode = 1;                                          // RLE block
         else if (m < 64) mode = 0;                                            // raw

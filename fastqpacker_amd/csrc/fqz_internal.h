@@ -32,7 +32,7 @@ struct EncInfo {
     uint32_t arena_used;    // bytes of the main arena in use
     uint32_t npos_used;
     uint32_t index_overflow; // a 4 KiB tile holds more lines than its tile-local slot (k_line_local)
-    uint32_t pad0;
+    uint32_t n_xgroups;     // all chunk groups = zstd frames, the Raw ones of the packed bases included (k_xxh)
     unsigned long long error_key; // (record << 8 | check order << 4 | code index), min wins
     unsigned long long out_len;
     unsigned long long stream_raw[FQZ_NS];

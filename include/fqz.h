@@ -58,7 +58,8 @@ typedef enum {
     FQZ_E_NO_DEVICE = -31,     /* no HIP device: the product path never falls back to CPU */
     FQZ_E_ARG = -32,
     FQZ_E_TOO_LARGE = -33,     /* batch >= 2 GiB of FASTQ text (device offsets are 32 bits); slice the input */
-    FQZ_E_IO = -34
+    FQZ_E_IO = -34,
+    FQZ_E_CHECKSUM = -35      /* a zstd frame's Content_Checksum does not match its decoded content */
 } fqz_status;
 
 const char *fqz_strerror(int status);
@@ -105,6 +106,9 @@ int fqz_read_block_header(const uint8_t *in, size_t n, uint8_t version, fqz_bloc
 /* ---- the per-block hot path (host buffers in, host buffers out) ---------- */
 /* Upper bound of fqz_encode_block / fqz_encode_batch output for n_bytes of FASTQ. */
 size_t fqz_encode_bound(size_t n_bytes);
+/* The same for blocks of records_per_block records (0 = FQZ_DEFAULT_BLOCK_SIZE): small blocks pay a block header and six
+ * payload framings (index, frame header, checksum) each. */
+size_t fqz_encode_bound_blocks(size_t n_bytes, uint32_t records_per_block);
 
 /* Replaces compressBlockWithBuffers (compress.go:471-555).  `fastq` holds whole
  * 4-line records (what fqparser.ReadBatch handed to the block codec); the GPU

@@ -303,12 +303,15 @@ static size_t huf_stream(const uint8_t *src, size_t n, const uint16_t *code, con
  * description, the others are "treeless" (Literals_Block_Type 3, RFC 8878 3.1.1.3.1.1: reuse the previous table).
  * On the GPU the table build (sort, Huffman merge, FSE weight coding) is a quarter of the LDS traffic of a chunk; a
  * group pays it once for four blocks, and the decoder builds four times fewer tables. */
-size_t fqzo_encode_group(const uint8_t *src, size_t M, int last, uint8_t *dst)
+static size_t encode_group_ex(const uint8_t *src, size_t M, int last, int force_raw, uint8_t *dst);
+size_t fqzo_encode_group(const uint8_t *src, size_t M, int last, uint8_t *dst) { return encode_group_ex(src, M, last, 0, dst); }
+static size_t encode_group_ex(const uint8_t *src, size_t M, int last, int force_raw, uint8_t *dst)
 {
     uint32_t count[256] = {0};
     for (size_t i = 0; i < M; i++) count[src[i]]++;
     int huff = 1;
-    if (count[src[0]] == M) huff = 0;          /* one symbol: every chunk is an RLE block */
+    if (force_raw) huff = 0;                   /* 2-bit packed bases: Raw blocks by definition (FQZ-H2), no histogram at all */
+    else if (count[src[0]] == M) huff = 0;     /* one symbol: every chunk is an RLE block */
     else if (M < 64) huff = 0;
     else {   /* near-flat histogram: collision entropy -log2(sum p^2) >= log2(230) = 7.85 bits bounds the Shannon entropy
               * from below, so a Huffman table could save < 2 %: store raw (this is what 2-bit packed bases look like) */
@@ -332,8 +335,8 @@ size_t fqzo_encode_group(const uint8_t *src, size_t M, int last, uint8_t *dst)
         const size_t m = M - off < FQZO_CHUNK ? M - off : FQZO_CHUNK;
         const uint8_t *c = src + off;
         const int lastblk = last && off + m == M;
-        int same = 1;
-        for (size_t i = 1; i < m; i++) if (c[i] != c[0]) { same = 0; break; }
+        int same = !force_raw;
+        for (size_t i = 1; same && i < m; i++) if (c[i] != c[0]) same = 0;
         if (same) { /* RLE block */
             put_block_header(out, lastblk, 1, (uint32_t)m);
             out[3] = c[0];
@@ -396,29 +399,97 @@ size_t fqzo_encode_chunk(const uint8_t *src, size_t m, int last, uint8_t *dst) {
 /* frame                                                                  */
 /* ===================================================================== */
 
+/* XXH64 (Y. Collet's public algorithm): zstd's Content_Checksum is its low 32 bits over the frame's content, seed 0
+ * (RFC 8878 3.1.1).  The reference keeps this checksum on purpose (PERFORMANCE.md E033, README.md:87). */
+#define XP1 0x9E3779B185EBCA87ULL
+#define XP2 0xC2B2AE3D27D4EB4FULL
+#define XP3 0x165667B19E3779F9ULL
+#define XP4 0x85EBCA77C2B2AE63ULL
+#define XP5 0x27D4EB2F165667C5ULL
+static inline uint64_t xrotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t xread64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static inline uint32_t xread32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static inline uint64_t xround(uint64_t acc, uint64_t in) { return xrotl(acc + in * XP2, 31) * XP1; }
+static inline uint64_t xmerge(uint64_t acc, uint64_t v) { return (acc ^ xround(0, v)) * XP1 + XP4; }
+uint64_t fqzo_xxh64(const uint8_t *p, size_t len, uint64_t seed)
+{
+    const uint8_t *end = p + len;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + XP1 + XP2, v2 = seed + XP2, v3 = seed, v4 = seed - XP1;
+        const uint8_t *lim = end - 32;
+        do {
+            v1 = xround(v1, xread64(p)); v2 = xround(v2, xread64(p + 8)); v3 = xround(v3, xread64(p + 16)); v4 = xround(v4, xread64(p + 24));
+            p += 32;
+        } while (p <= lim);
+        h = xrotl(v1, 1) + xrotl(v2, 7) + xrotl(v3, 12) + xrotl(v4, 18);
+        h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+    } else h = seed + XP5;
+    h += (uint64_t)len;
+    while (p + 8 <= end) { h ^= xround(0, xread64(p)); h = xrotl(h, 27) * XP1 + XP4; p += 8; }
+    if (p + 4 <= end) { h ^= (uint64_t)xread32(p) * XP1; h = xrotl(h, 23) * XP2 + XP3; p += 4; }
+    while (p < end) { h ^= (uint64_t)(*p++) * XP5; h = xrotl(h, 11) * XP1; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    return h;
+}
+
+/* "FQZ-H2" payload of one pre-entropy stream of n bytes (n == 0: a 0-byte payload):
+ *   [index]   a zstd SKIPPABLE frame (RFC 8878 3.1.2, magic 0x184D2A50; every zstd decoder, the reference's DecodeAll
+ *             included, skips it): 'FQZI', version 1, the stream id, the pre-entropy length, the number of zstd blocks and
+ *             the size of each (3 bytes, block header included) - what a parallel decoder needs to find every block
+ *             without walking the chain of block headers;
+ *   [frames]  one zstd frame per GROUP of FQZO_GROUP chunks (<= 64 KiB of the stream): Single_Segment, Frame_Content_Size,
+ *             Content_Checksum; one zstd block per 16 KiB chunk as in FQZ-H1 (one Huffman table per group, the later
+ *             blocks treeless).  The 2-bit packed bases (stream 0) are Raw blocks by definition.
+ * Frames are independent, so encoder and decoder work on every group in parallel and the content checksum (an
+ * inherently serial hash) runs over 64 KiB at a time, one hash per four lanes. */
+#define FQZO_IDX_HDR 24 /* magic 4 + size 4 + 'FQZI' 4 + version, stream, flags 4 + raw length 4 + block count 4 */
+static inline void put32le(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
 size_t fqzo_entropy_bound(size_t n)
 {
     if (!n) return 0;
-    size_t chunks = (n + FQZO_CHUNK - 1) / FQZO_CHUNK;
-    return 10 + n + 3 * chunks;
+    const size_t chunks = (n + FQZO_CHUNK - 1) / FQZO_CHUNK, groups = (chunks + FQZO_GROUP - 1) / FQZO_GROUP;
+    return FQZO_IDX_HDR + 3 * chunks + groups * (7 + 4) + n + 3 * chunks;
 }
 
-size_t fqzo_entropy_encode(const uint8_t *src, size_t n, uint8_t *dst)
+size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint8_t *dst)
 {
     if (!n) return 0;
-    uint8_t *op = dst;
-    op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
-    op[4] = 0x80; /* FCS 4 bytes, not single-segment, no checksum, no dict */
-    op[5] = 0x38; /* window 128 KiB */
-    op[6] = (uint8_t)n; op[7] = (uint8_t)(n >> 8); op[8] = (uint8_t)(n >> 16); op[9] = (uint8_t)(n >> 24);
-    op += 10;
+    const size_t chunks = (n + FQZO_CHUNK - 1) / FQZO_CHUNK;
+    uint8_t *idx = dst, *op = dst + FQZO_IDX_HDR + 3 * chunks;
+    put32le(idx, 0x184D2A50u);
+    put32le(idx + 4, (uint32_t)(FQZO_IDX_HDR - 8 + 3 * chunks));
+    idx[8] = 'F'; idx[9] = 'Q'; idx[10] = 'Z'; idx[11] = 'I';
+    idx[12] = 1; idx[13] = (uint8_t)stream; idx[14] = 0; idx[15] = 0;
+    put32le(idx + 16, (uint32_t)n);
+    put32le(idx + 20, (uint32_t)chunks);
+    uint8_t *ent = idx + FQZO_IDX_HDR;
     const size_t G = (size_t)FQZO_GROUP * FQZO_CHUNK;
     for (size_t off = 0; off < n; off += G) {
-        size_t M = n - off < G ? n - off : G;
-        op += fqzo_encode_group(src + off, M, off + M == n, op);
+        const size_t M = n - off < G ? n - off : G;
+        op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
+        if (M < 256) { op[4] = 0x24; op[5] = (uint8_t)M; op += 6; }                       /* single segment, checksum, FCS 1 byte */
+        else { op[4] = 0x64; op[5] = (uint8_t)(M - 256); op[6] = (uint8_t)((M - 256) >> 8); op += 7; } /* FCS 2 bytes, value - 256 */
+        const size_t body = encode_group_ex(src + off, M, 1, stream == 0, op);
+        /* the index lists the size of every zstd block of the group */
+        for (size_t q = 0; q < body;) {
+            const uint32_t bh = op[q] | ((uint32_t)op[q + 1] << 8) | ((uint32_t)op[q + 2] << 16);
+            const uint32_t type = (bh >> 1) & 3, bs = bh >> 3;
+            const uint32_t sz = 3 + (type == 1 ? 1u : bs);
+            ent[0] = (uint8_t)sz; ent[1] = (uint8_t)(sz >> 8); ent[2] = (uint8_t)(sz >> 16);
+            ent += 3;
+            q += sz;
+        }
+        op += body;
+        put32le(op, (uint32_t)fqzo_xxh64(src + off, M, 0));
+        op += 4;
     }
     return (size_t)(op - dst);
 }
+
+/* a stream of no particular kind: Huffman-coded like the quality stream */
+size_t fqzo_entropy_encode(const uint8_t *src, size_t n, uint8_t *dst) { return fqzo_entropy_encode_stream(src, n, 1, dst); }
 
 /* ===================================================================== */
 /* decoder (subset: no sequences)                                         */
@@ -716,19 +787,53 @@ static int parse_frame_header(const uint8_t *src, size_t n, size_t *hdr_size, lo
     return 0;
 }
 
+static int is_skippable(const uint8_t *p, size_t n)
+{
+    return n >= 8 && (p[0] & 0xF0) == 0x50 && p[1] == 0x2A && p[2] == 0x4D && p[3] == 0x18;
+}
+
+/* pre-entropy bytes of a payload: the sum of the Frame_Content_Size fields of its frames (every frame must state it) */
 long fqzo_entropy_content_size(const uint8_t *src, size_t n)
 {
-    if (!n) return 0;
-    size_t h; long fcs; int ck;
-    if (parse_frame_header(src, n, &h, &fcs, &ck) < 0) return FQZO_E_ENTROPY;
-    return fcs;
+    size_t ip = 0;
+    uint64_t total = 0;
+    while (ip < n) {
+        if (is_skippable(src + ip, n - ip)) {
+            const uint32_t sz = src[ip + 4] | ((uint32_t)src[ip + 5] << 8) | ((uint32_t)src[ip + 6] << 16) | ((uint32_t)src[ip + 7] << 24);
+            if ((uint64_t)sz + 8 > n - ip) return FQZO_E_ENTROPY;
+            ip += 8 + (size_t)sz;
+            continue;
+        }
+        size_t h; long fcs; int ck;
+        if (parse_frame_header(src + ip, n - ip, &h, &fcs, &ck) < 0 || fcs < 0) return FQZO_E_ENTROPY;
+        ip += h;
+        for (;;) {
+            if (ip + 3 > n) return FQZO_E_ENTROPY;
+            const uint32_t bh = src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16);
+            const uint32_t type = (bh >> 1) & 3, bs = bh >> 3;
+            const size_t adv = 3 + (type == 1 ? 1u : bs);
+            if (type == 3 || adv > n - ip) return FQZO_E_ENTROPY;
+            ip += adv;
+            if (bh & 1) break;
+        }
+        if (ck) { if (ip + 4 > n) return FQZO_E_ENTROPY; ip += 4; }
+        total += (uint64_t)fcs;
+        if (total > 0x7FFFFFFFull) return FQZO_E_ENTROPY;
+    }
+    return (long)total;
 }
 
 long fqzo_entropy_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
 {
     size_t out = 0;
     size_t ip = 0;
-    while (ip < n) { /* concatenated frames are legal; DecodeAll decodes them all */
+    while (ip < n) { /* concatenated frames are legal; DecodeAll decodes them all and skips skippable frames */
+        if (is_skippable(src + ip, n - ip)) {
+            const uint32_t sz = src[ip + 4] | ((uint32_t)src[ip + 5] << 8) | ((uint32_t)src[ip + 6] << 16) | ((uint32_t)src[ip + 7] << 24);
+            if ((uint64_t)sz + 8 > n - ip) return FQZO_E_ENTROPY;
+            ip += 8 + (size_t)sz;
+            continue;
+        }
         size_t h; long fcs; int ck;
         if (parse_frame_header(src + ip, n - ip, &h, &fcs, &ck) < 0) return FQZO_E_ENTROPY;
         ip += h;
@@ -762,7 +867,12 @@ long fqzo_entropy_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
         }
         free(hs);
         if (err) return err;
-        if (ck) { if (ip + 4 > n) return FQZO_E_ENTROPY; ip += 4; /* XXH64 low 32 bits: not verified */ }
+        if (ck) { /* Content_Checksum: low 32 bits of XXH64 over the frame's content; a mismatch is an error */
+            if (ip + 4 > n) return FQZO_E_ENTROPY;
+            const uint32_t want = src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16) | ((uint32_t)src[ip + 3] << 24);
+            if ((uint32_t)fqzo_xxh64(dst + frame_start, out - frame_start, 0) != want) return FQZO_E_ENTROPY;
+            ip += 4;
+        }
         if (fcs >= 0 && (size_t)fcs != out - frame_start) return FQZO_E_ENTROPY;
     }
     return (long)out;

@@ -511,7 +511,7 @@ static void encode_block_job(enc_job *j)
             comp[k] = s.len[k] ? zs.compress(out + w, cap - w, s.data[k], s.len[k], 1) : 0;
             if (zs.is_error(comp[k])) { free(out); fqzo_streams_free(&s); j->err = FQZO_E_ENTROPY; return; }
         } else {
-            comp[k] = fqzo_entropy_encode(s.data[k], s.len[k], out + w);
+            comp[k] = fqzo_entropy_encode_stream(s.data[k], s.len[k], k, out + w);
         }
         w += comp[k];
     }

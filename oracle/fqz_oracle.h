@@ -153,6 +153,10 @@ long fqzo_join_block_size(const uint8_t *const data[FQZO_NSTREAMS], const size_t
 size_t fqzo_entropy_bound(size_t n);
 /* Returns frame size; n==0 -> 0 bytes (klauspost EncodeAll without zero frames). */
 size_t fqzo_entropy_encode(const uint8_t *src, size_t n, uint8_t *dst);
+/* the payload of stream `stream` (0 seq .. 5 lengths) of a block: the 2-bit packed bases are Raw by definition */
+size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint8_t *dst);
+/* XXH64 (zstd content checksum = its low 32 bits, seed 0) */
+uint64_t fqzo_xxh64(const uint8_t *p, size_t len, uint64_t seed);
 /* Decoder for any zstd frame made only of Raw / RLE / Compressed blocks whose
  * Compressed blocks carry zero sequences (Huffman, raw or RLE literals).
  * Replaces zstd.Decoder.DecodeAll (compress.go:785-814) for our own output.

@@ -91,6 +91,10 @@ def lib():
         L.fqzo_entropy_bound.argtypes = [C.c_size_t]
         L.fqzo_entropy_encode.restype = C.c_size_t
         L.fqzo_entropy_encode.argtypes = [C.c_char_p, C.c_size_t, u8p]
+        L.fqzo_entropy_encode_stream.restype = C.c_size_t
+        L.fqzo_entropy_encode_stream.argtypes = [C.c_char_p, C.c_size_t, C.c_int, u8p]
+        L.fqzo_xxh64.restype = C.c_uint64
+        L.fqzo_xxh64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
         L.fqzo_entropy_decode.restype = C.c_long
         L.fqzo_entropy_decode.argtypes = [C.c_char_p, C.c_size_t, u8p, C.c_size_t]
         L.fqzo_entropy_content_size.restype = C.c_long
@@ -207,11 +211,40 @@ def join_block(streams, num_records, enc, cap=None):
     return bytes(out[:r])
 
 
-def entropy_encode(src: bytes) -> bytes:
+def entropy_encode(src: bytes, stream: int = 1) -> bytes:
+    """FQZ-H2 payload of one pre-entropy stream (stream 0 = 2-bit packed bases: Raw blocks by definition)."""
     cap = lib().fqzo_entropy_bound(len(src)) + 16
     out = bytearray(cap)
-    n = lib().fqzo_entropy_encode(src, len(src), _u8(out))
+    n = lib().fqzo_entropy_encode_stream(src, len(src), stream, _u8(out))
     return bytes(out[:n])
+
+
+def xxh64(data: bytes, seed: int = 0) -> int:
+    return lib().fqzo_xxh64(data, len(data), seed)
+
+
+def payload_frames(payload: bytes):
+    """Splits an FQZ-H2 payload into (index frame or None, [zstd frames]) by walking the frame / block headers."""
+    idx, frames, ip, n = None, [], 0, len(payload)
+    while ip < n:
+        if payload[ip + 1:ip + 4] == b"\x2a\x4d\x18" and (payload[ip] & 0xF0) == 0x50:
+            sz = int.from_bytes(payload[ip + 4:ip + 8], "little")
+            idx = payload[ip:ip + 8 + sz]
+            ip += 8 + sz
+            continue
+        assert payload[ip:ip + 4] == bytes.fromhex("28b52ffd")
+        fhd = payload[ip + 4]
+        single, ck, fcs_flag = (fhd >> 5) & 1, (fhd >> 2) & 1, fhd >> 6
+        q = ip + 5 + (0 if single else 1) + [single, 2, 4, 8][fcs_flag]
+        while True:
+            bh = int.from_bytes(payload[q:q + 3], "little")
+            q += 3 + (1 if (bh >> 1) & 3 == 1 else bh >> 3)
+            if bh & 1:
+                break
+        q += 4 * ck
+        frames.append(payload[ip:q])
+        ip = q
+    return idx, frames
 
 
 def entropy_decode(frame: bytes, cap=None) -> bytes:
@@ -243,7 +276,7 @@ def compress(fastq, block_size=0, workers=1, batch_records=0, entropy=0) -> byte
     a = np.frombuffer(fastq, dtype=np.uint8) if not isinstance(fastq, np.ndarray) else fastq
     cap = lib().fqzo_compress_bound(a.size)
     if batch_records:  # tiny blocks: 36-byte block headers and six frame headers per block dwarf the library's bound
-        cap += (int(np.count_nonzero(a == 10)) // 4 // batch_records + 2) * 160
+        cap += (int(np.count_nonzero(a == 10)) // 4 // batch_records + 2) * 320
     out = np.empty(cap, dtype=np.uint8)
     opt = Options(block_size, workers, batch_records, entropy)
     r = lib().fqzo_compress(a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, C.byref(opt))

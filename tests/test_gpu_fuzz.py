@@ -36,7 +36,7 @@ def _gpu_encode_blocks(fq, text, block, enc):
     import torch
     dev = torch.device("cuda:0")
     t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev) if len(text) else torch.empty(0, dtype=torch.uint8, device=dev)
-    out = torch.empty(len(text) * 2 + 65536, dtype=torch.uint8, device=dev)
+    out = torch.empty(fq.lib().fqz_encode_bound_blocks(len(text), block), dtype=torch.uint8, device=dev)
     res = fq.compress.encode_batch_dev(t.data_ptr() if len(text) else 0, len(text), out.data_ptr(), out.numel(), records_per_block=block,
                                        qual_encoding=enc, final=True)
     return out[: res.out_len].cpu().numpy().tobytes(), res
@@ -108,6 +108,10 @@ def test_corrupted_containers_are_refused_or_decoded_never_crash(fq):
                 out = fq.compress.Decompress(bytes(z))
                 n_ok += 1
                 assert isinstance(out, bytes)
+                # our own frames carry content checksums (as the reference's do): damage is either refused or harmless
+                # (a field no decoder reads, the index, which is only a hint) - never silently wrong text
+                if base is ours and kind != 2:
+                    assert out == text, "trial %d: corrupted container decoded to different text without an error" % trial
             except fq.FqzError:
                 n_err += 1
     assert n_err > 40 and n_err + n_ok == 80

@@ -32,8 +32,11 @@ def test_frames_decode_with_libzstd():
         if not data:
             assert f == b""
             continue
-        assert f[:4] == bytes.fromhex("28b52ffd")
-        assert O.zstd_decompress(f, len(data)) == data, name
+        idx, frames = O.payload_frames(f)
+        assert idx is not None and f.startswith(idx) and idx[8:12] == b"FQZI"      # skippable index frame first
+        assert len(frames) == (len(data) + 65535) // 65536                            # one zstd frame per 64 KiB group
+        assert all(fr[:4] == bytes.fromhex("28b52ffd") for fr in frames)
+        assert O.zstd_decompress(f, len(data)) == data, name                        # libzstd skips the index, verifies every checksum
         assert O.entropy_decode(f) == data, name
 
 
@@ -44,7 +47,8 @@ def test_own_decoder_roundtrip_and_rejects_garbage():
     f = bytearray(O.entropy_encode(bytes(np.random.default_rng(1).integers(0, 4, 20000, dtype=np.uint8))))
     with pytest.raises(O.OracleError):
         O.entropy_decode(bytes(f[:-3]), 20000)
-    f[0] ^= 1
+    idx, _ = O.payload_frames(bytes(f))
+    f[len(idx)] ^= 1          # the magic of the first zstd frame (byte 0 belongs to the skippable index frame, whose 16 magics differ in that nibble)
     with pytest.raises(O.OracleError):
         O.entropy_decode(bytes(f), 20000)
 
@@ -101,13 +105,62 @@ def test_group_shapes_use_treeless_blocks():
     """the blocks after the first Compressed block of a group are treeless (Literals_Block_Type 3)"""
     data = dict(O.group_cases())["two-groups-and-a-tail"]
     f = O.entropy_encode(data)
-    pos, types = 10, []
-    while True:
-        bh = int.from_bytes(f[pos:pos + 3], "little")
-        last, btype, bs = bh & 1, (bh >> 1) & 3, bh >> 3
-        types.append((btype, f[pos + 3] & 3 if btype == 2 else None))
-        pos += 3 + (1 if btype == 1 else bs)
-        if last:
-            break
-    assert pos == len(f)
+    idx, frames = O.payload_frames(f)
+    types, sizes = [], []
+    for fr in frames:                       # one frame per group
+        pos = 7 if fr[4] >> 6 else 6        # magic, FHD, FCS (2 bytes from 256 bytes of content on)
+        while True:
+            bh = int.from_bytes(fr[pos:pos + 3], "little")
+            last, btype, bs = bh & 1, (bh >> 1) & 3, bh >> 3
+            types.append((btype, fr[pos + 3] & 3 if btype == 2 else None))
+            step = 3 + (1 if btype == 1 else bs)
+            sizes.append(step)
+            pos += step
+            if last:
+                break
+        assert pos + 4 == len(fr)            # the content checksum ends the frame
+    # the index frame lists the size of every zstd block
+    n_blocks = int.from_bytes(idx[20:24], "little")
+    assert int.from_bytes(idx[16:20], "little") == len(data) and n_blocks == len(sizes)
+    assert [int.from_bytes(idx[24 + 3 * k:27 + 3 * k], "little") for k in range(n_blocks)] == sizes
     assert types == [(2, 2), (2, 3), (2, 3), (2, 3)] * 2 + [(2, 2), (2, 3)]
+
+
+def test_xxh64_known_answers():
+    """XXH64 known answers (public test vectors of the algorithm): the zstd content checksum is its low 32 bits."""
+    assert O.xxh64(b"") == 0xEF46DB3751D8E999
+    assert O.xxh64(b"", 1) == 0xD5AFBA1336A3BE4B
+    assert O.xxh64(b"a") == 0xD24EC4F1A98C6E5B
+    assert O.xxh64(b"abc") == 0x44BC2CF5AD770999
+    assert O.xxh64(b"Nobody inspects the spammish repetition") == 0xFBCEA83C8A378BF1
+
+
+@needs_zstd
+def test_content_checksum_is_emitted_and_verified():
+    """The reference keeps zstd's frame checksum on purpose (PERFORMANCE.md E033, README.md:87): every frame of a payload
+    carries one, libzstd accepts it, and one flipped payload bit is an error for libzstd and for the oracle decoder."""
+    rng = np.random.default_rng(5)
+    data = bytes(np.minimum(rng.geometric(0.4, 200000) - 1, 40).astype(np.uint8))
+    f = O.entropy_encode(data)
+    idx, frames = O.payload_frames(f)
+    pos = len(idx)
+    for k, fr in enumerate(frames):
+        assert fr[4] & 0x04                                   # Content_Checksum_flag
+        want = O.xxh64(data[65536 * k:65536 * (k + 1)]) & 0xFFFFFFFF
+        assert int.from_bytes(fr[-4:], "little") == want
+        pos += len(fr)
+    assert pos == len(f)
+    # raw stream (2-bit packed bases): Raw blocks only, still checksummed
+    f0 = O.entropy_encode(data, stream=0)
+    assert O.zstd_decompress(f0, len(data)) == data and O.entropy_decode(f0) == data
+    assert len(f0) > len(data)
+    bad = 0
+    for off in (len(idx) + 40, len(idx) + len(frames[0]) // 2, len(f) - 1, len(f) - 9):
+        g = bytearray(f)
+        g[off] ^= 0x10
+        with pytest.raises(ValueError):
+            O.zstd_decompress(bytes(g), len(data))
+        with pytest.raises(O.OracleError):
+            O.entropy_decode(bytes(g), len(data))
+        bad += 1
+    assert bad == 4
