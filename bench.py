@@ -27,6 +27,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=float, default=1e9, help="FASTQ bytes per rank (config 2: synthetic 1 GB)")
+    ap.add_argument("--reads", type=float, default=0, help="reads per rank instead of --bytes (config 2's other reading: 1e7 reads = 3.5 GB, run as "
+                    "several device batches of whole 100k-read blocks back to back)")
     ap.add_argument("--profile", type=int, default=1, help="bracket kernels with HIP events (roofline.achieved)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--decode-steps", type=int, default=3)
@@ -36,41 +38,56 @@ def parse_args():
 
 
 def cpu_baseline(text_np, want_seconds=20.0):
-    """Oracle (CPU restatement of the reference pipeline, libzstd level 1 entropy stage when the system
-    library is present) timed on the host cores over a bounded sample of the same workload."""
+    """Oracle (CPU restatement of the reference pipeline: one parser thread, W workers each owning an entropy context,
+    ordered writer; entropy stage = libzstd level 1 when the system library is present) timed on the host cores over a
+    bounded sample of the same workload, at W = all cores and at W = 1.  Protocol of
+    scripts/benchmark_fqpack_9gb.sh:71-96: one verified run, then timed runs, mean."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O  # checker / baseline only
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     entropy = 1 if O.lib().fqzo_libzstd_version() else 0
-    # sample: whole 100k-record blocks, sized so the leg takes ~10-30 s of CPU work
     rec_bytes = 351
-    blocks = max(1, min(int(text_np.size // (rec_bytes * 100000)), max(2, cores)))
-    n = min(text_np.size, blocks * 100000 * rec_bytes)
-    cut = text_np[:n]
-    # cut on a record boundary: every record of this workload starts with "@SIM:"
-    tail = bytes(cut[-4096:])
-    k = tail.rfind(b"\n@SIM:")
-    cut = cut[: n - len(tail) + k + 1]
-    t0 = time.perf_counter()
-    z = O.compress(cut, workers=cores, entropy=entropy)
-    dt = time.perf_counter() - t0
-    reps = 1
-    if dt < want_seconds / 4:  # repeat to get a stable number, still bounded
-        reps = int(min(8, max(1, (want_seconds / 2) / max(dt, 1e-3))))
+
+    def sample(blocks):
+        n = min(text_np.size, blocks * 100000 * rec_bytes)
+        cut = text_np[:n]
+        tail = bytes(cut[-4096:])  # cut on a record boundary: every record of this workload starts with "@SIM:"
+        k = tail.rfind(b"\n@SIM:")
+        return cut[: n - len(tail) + k + 1]
+
+    def timed(cut, workers, budget):
+        z = O.compress(cut, workers=workers, entropy=entropy)            # the verified run
+        ok = O.decompress(z, workers=workers) == bytes(cut)
         t0 = time.perf_counter()
-        for _ in range(reps):
-            z = O.compress(cut, workers=cores, entropy=entropy)
-        dt = (time.perf_counter() - t0) / reps
-    t0 = time.perf_counter()
-    back = O.decompress(z, workers=cores)
-    ddt = time.perf_counter() - t0
-    ok = back == bytes(cut)
+        z = O.compress(cut, workers=workers, entropy=entropy)
+        dt = time.perf_counter() - t0
+        reps = 1
+        if dt < budget / 4:
+            reps = int(min(8, max(3, budget / 2 / max(dt, 1e-3))))
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                z = O.compress(cut, workers=workers, entropy=entropy)
+            dt = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        O.decompress(z, workers=workers)
+        ddt = time.perf_counter() - t0
+        return cut.size / dt / 1e6, cut.size / ddt / 1e6, cut.size / len(z), ok, reps
+
+    total_blocks = max(1, int(text_np.size // (rec_bytes * 100000)))
+    cut_all = sample(total_blocks)                                      # every block of the batch: jobs >= cores needs blocks >= cores
+    v_all, d_all, ratio, ok_all, reps_all = timed(cut_all, cores, want_seconds * 0.6)
+    cut_one = sample(min(total_blocks, 3))                              # W = 1: ~100 MB keeps the leg within seconds
+    v_one, d_one, _, ok_one, reps_one = timed(cut_one, 1, want_seconds * 0.4)
+    ent = "libzstd-%d level 1 entropy stage" % O.lib().fqzo_libzstd_version() if entropy else "its own Huffman entropy stage"
+    jobs = int(cut_all.size // (rec_bytes * 100000)) + 1
     return {
-        "value": round(cut.size / dt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
-        "sample": "%d MB (%d blocks of 100k reads) of the same synthetic FASTQ, %d timed pass(es), oracle C pipeline with %s"
-                  % (cut.size // 1000000, blocks, reps, "libzstd-%d level 1 entropy stage" % O.lib().fqzo_libzstd_version() if entropy
-                     else "its own Huffman entropy stage"),
-        "decode_MBps": round(cut.size / ddt / 1e6, 1), "ratio": round(cut.size / len(z), 3), "roundtrip_ok": ok,
+        "value": round(v_all, 1), "unit": "MB/s", "cores": cores, "kind": "port",
+        "sample": "%d MB (%d blocks of 100k reads = %d block jobs for %d worker threads: %.0f %% of the cores can be busy) of the same "
+                  "synthetic FASTQ, 1 verified + %d timed pass(es), oracle C pipeline (CPU restatement, not the reference Go binary) with %s"
+                  % (cut_all.size // 1000000, jobs, jobs, cores, 100.0 * min(1.0, jobs / cores), reps_all, ent),
+        "decode_MBps": round(d_all, 1), "ratio": round(ratio, 3), "roundtrip_ok": bool(ok_all and ok_one),
+        "w1": {"value": round(v_one, 1), "unit": "MB/s", "cores": 1, "decode_MBps": round(d_one, 1),
+               "sample": "%d MB, 1 verified + %d timed pass(es), one worker thread" % (cut_one.size // 1000000, reps_one)},
     }
 
 
@@ -92,35 +109,56 @@ def main():
     import ctypes as C
     import fastqpacker_amd as fq
     from fastqpacker_amd import compress
+    from fastqpacker_amd import sharding
     from fastqpacker_amd._lib import BatchResult, lib
 
-    # ---- workload: config 2 of BASELINE.json, one shard per rank ---------------------------------
-    n_bytes = int(a.bytes)
-    n_rec = n_bytes // 351 + 1
-    text_np, wrote = compress.synth_fastq(n_rec, first_record=rank * n_rec, quality_profile=a.quality_profile, cap=n_bytes + 4096)
-    text_np = text_np[: min(text_np.size, n_bytes)]
-    k = bytes(text_np[-4096:]).rfind(b"\n@SIM:")          # end on a record boundary
-    text_np = text_np[: text_np.size - 4096 + k + 1]
-    d_text = torch.from_numpy(text_np).to(dev)
-    d_out = torch.empty(int(lib().fqz_encode_bound(text_np.size)) // 2 + (1 << 20), dtype=torch.uint8, device=dev)
+    # ---- workload: config 2 of BASELINE.json, one shard per rank, as one or more device batches (< 2 GiB each) ----------
+    RPB = fq.DEFAULT_BLOCK_SIZE
+    batches = []  # (text as numpy, device tensor)
+    if a.reads:
+        total_reads = int(a.reads)
+        per_batch = (int(1.9e9) // 351 // RPB) * RPB                      # whole 100k-read blocks per batch
+        r0 = 0
+        while r0 < total_reads:
+            nr = min(per_batch, total_reads - r0)
+            t_np, wrote = compress.synth_fastq(nr, first_record=rank * total_reads + r0, quality_profile=a.quality_profile)
+            assert wrote == nr
+            batches.append(t_np)
+            r0 += nr
+        workload = "synthetic 150 bp Phred+33 FASTQ, %d reads = %.2f GB per GPU (BASELINE.json configs[1] in its '10 M reads' reading), " \
+                   "%d device batches of whole 100k-read blocks back to back" % (total_reads, sum(b.size for b in batches) / 1e9, len(batches))
+    else:
+        n_bytes = int(a.bytes)
+        n_rec = n_bytes // 351 + 1
+        t_np, wrote = compress.synth_fastq(n_rec, first_record=rank * n_rec, quality_profile=a.quality_profile, cap=n_bytes + 4096)
+        t_np = t_np[: min(t_np.size, n_bytes)]
+        k = bytes(t_np[-4096:]).rfind(b"\n@SIM:")                          # end on a record boundary
+        batches.append(t_np[: t_np.size - 4096 + k + 1])
+        workload = "synthetic 150 bp Phred+33 FASTQ, %.2f GB per GPU (BASELINE.json configs[1] in its '1 GB' reading), one device batch" \
+                   % (batches[0].size / 1e9)
+    workload += ", device-resident, 100k-record blocks, quality profile %d" % a.quality_profile
+    d_texts = [torch.from_numpy(b).to(dev) for b in batches]
+    d_outs = [torch.empty(int(lib().fqz_encode_bound(b.size)) // 2 + (1 << 20), dtype=torch.uint8, device=dev) for b in batches]
+    in_bytes = int(sum(b.size for b in batches))
     ctx = fq.Ctx(local_rank)
     stream = torch.cuda.current_stream(dev)
     sptr = C.c_void_p(stream.cuda_stream)
-    max_blocks = text_np.size // (351 * 100000) + 8
-    offs = (C.c_uint64 * max_blocks)()
-    lens = (C.c_uint64 * max_blocks)()
-    res = BatchResult()
+    max_blocks = max(b.size for b in batches) // (351 * RPB) + 8
+    offs = [(C.c_uint64 * max_blocks)() for _ in batches]
+    lens = [(C.c_uint64 * max_blocks)() for _ in batches]
+    ress = [BatchResult() for _ in batches]
+    world_blocks = max_blocks * len(batches)
 
     def encode_step():
-        fq._lib.check(lib().fqz_encode_batch_dev(ctx.handle, d_text.data_ptr(), text_np.size, fq.DEFAULT_BLOCK_SIZE, fq.ENCODING_PHRED33,
-                                                 fq.BATCH_FINAL, d_out.data_ptr(), d_out.numel(), C.byref(res), offs, lens, max_blocks, sptr))
+        for i, b in enumerate(batches):
+            fq._lib.check(lib().fqz_encode_batch_dev(ctx.handle, d_texts[i].data_ptr(), b.size, RPB, fq.ENCODING_PHRED33,
+                                                     fq.BATCH_FINAL, d_outs[i].data_ptr(), d_outs[i].numel(), C.byref(ress[i]), offs[i], lens[i],
+                                                     max_blocks, sptr))
         if world > 1:
-            # container index: all-gather of per-block compressed sizes -> exclusive prefix = file offsets (RCCL over xGMI)
-            mine = torch.zeros(max_blocks, dtype=torch.int64, device=dev)
-            mine[: res.n_blocks] = torch.tensor(list(lens[: res.n_blocks]), dtype=torch.int64, device=dev)
-            allsz = torch.empty(world * max_blocks, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allsz, mine)
-            return torch.cumsum(allsz, 0)
+            # container index: all-gather of per-block compressed sizes -> exclusive prefix = file offsets (RCCL over xGMI);
+            # the function the world-size-2 gloo test covers
+            mine = [int(x) for i in range(len(batches)) for x in lens[i][: ress[i].n_blocks]]
+            return sharding.block_offsets_allgather(mine, world_blocks, device=dev)
         return None
 
     for _ in range(a.warmup):
@@ -132,13 +170,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        encode_step()
+        placed = encode_step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kern = ctx.profile_read() if a.profile else {}
     ctx.profile(False)
+    launches_per_step = len(batches)
     if a.profile:  # per-kernel breakdown of the rest of the pipeline: a separate, untimed pass with every kernel bracketed
         ctx.profile(1)
         for _ in range(3):
@@ -148,13 +187,14 @@ def main():
         ctx.profile(False)
         for k, v in allk.items():
             if k not in kern:
-                kern[k] = (v[0] / max(1, v[1]) * a.steps, a.steps)  # scaled to the timed region's step count
+                kern[k] = (v[0] / max(1, v[1]) * a.steps * launches_per_step, a.steps * launches_per_step)  # scaled to the timed region
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    in_bytes = text_np.size
-    out_bytes = int(res.out_len)
+    out_bytes = int(sum(int(r.out_len) for r in ress))
+    n_records = int(sum(int(r.n_records) for r in ress))
+    n_blocks = int(sum(int(r.n_blocks) for r in ress))
     total_in = torch.tensor([in_bytes], dtype=torch.float64, device=dev)
     total_out = torch.tensor([out_bytes], dtype=torch.float64, device=dev)
     if world > 1:
@@ -162,18 +202,38 @@ def main():
         dist.all_reduce(total_out)
     total_in, total_out = float(total_in.item()), float(total_out.item())
 
+    # ---- N > 1: the file the ranks would write (blocks at their all-gathered offsets) is checked once, outside the timed
+    #      region: block sizes of every rank, offsets = their exclusive prefix sum + 10, and the total
+    sharded_ok = None
+    if world > 1:
+        my_offs, file_total, allsz = placed
+        mine = [int(x) for i in range(len(batches)) for x in lens[i][: ress[i].n_blocks]]
+        ok = int(file_total) == int(total_out) + 10 and len(my_offs) == len(mine)
+        flat = allsz.reshape(-1).tolist()
+        run = 10
+        for r in range(world):
+            for k in range(world_blocks):
+                if r == rank and k < len(mine):
+                    ok = ok and my_offs[k] == run and mine[k] == flat[r * world_blocks + k]
+                run += flat[r * world_blocks + k]
+        tok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(tok, op=dist.ReduceOp.MIN)
+        sharded_ok = bool(tok.item())
+
     # ---- bit-exact gate + decode rate (rank-local) ------------------------------------------------
-    fqz_dev = d_out[:out_bytes].clone()
-    d_back = torch.empty(in_bytes + 4096, dtype=torch.uint8, device=dev)
-    dres = BatchResult()
+    fqz_devs = [d_outs[i][: int(ress[i].out_len)].clone() for i in range(len(batches))]
+    d_backs = [torch.empty(b.size + 4096, dtype=torch.uint8, device=dev) for b in batches]
+    dress = [BatchResult() for _ in batches]
     dkern = {}
 
     def decode_step():
-        fq._lib.check(lib().fqz_decode_batch_dev(ctx.handle, fqz_dev.data_ptr(), out_bytes, 2, fq.ENCODING_PHRED33, d_back.data_ptr(),
-                                                 d_back.numel(), C.byref(dres), sptr))
+        for i in range(len(batches)):
+            fq._lib.check(lib().fqz_decode_batch_dev(ctx.handle, fqz_devs[i].data_ptr(), fqz_devs[i].numel(), 2, fq.ENCODING_PHRED33,
+                                                     d_backs[i].data_ptr(), d_backs[i].numel(), C.byref(dress[i]), sptr))
     try:
         decode_step()
-        roundtrip_ok = bool(dres.out_len == in_bytes and torch.equal(d_back[:in_bytes], d_text))
+        roundtrip_ok = all(bool(dress[i].out_len == batches[i].size and torch.equal(d_backs[i][: batches[i].size], d_texts[i]))
+                           for i in range(len(batches)))
         torch.cuda.synchronize()
         if a.profile:
             ctx.profile(True)
@@ -201,42 +261,48 @@ def main():
         kernels = {k: round(v[0] / max(1, v[1]), 4) for k, v in kern.items()}  # avg ms per launch
         dom = max(kern, key=lambda k: kern[k][0])
         avg_s = kern[dom][0] / kern[dom][1] / 1e3
-        algorithmic = in_bytes + out_bytes  # B_in + B_out per launch
+        algorithmic = (in_bytes + out_bytes) / launches_per_step  # B_in + B_out per launch
         ach = algorithmic / avg_s / 1e9
         # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
         # separately; summary committed under profiles/): static evidence, not re-measured in this process
         traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")))
-            if abs(in_bytes - pmc.get("batch_bytes", in_bytes)) <= 0.01 * in_bytes:  # counters were taken on the default batch
-                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
+        for rnd in ("r02", "r01"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")))
+                if abs(in_bytes / launches_per_step - pmc.get("batch_bytes", 0)) <= 0.02 * in_bytes and dom in pmc["kernels"]:
+                    traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                    break
+            except Exception:
+                pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": algorithmic, "avg_launch_ms": round(avg_s * 1e3, 4),
-                "pipeline_GBps": round(algorithmic / (sum(v[0] for v in kern.values()) / a.steps / 1e3) / 1e9, 1)}
+                "algorithmic_bytes_per_launch": int(algorithmic), "avg_launch_ms": round(avg_s * 1e3, 4),
+                "pipeline_GBps": round((in_bytes + out_bytes) / (ms_per_step / 1e3) / 1e9, 1)}
+    res = ress[0]
+    sraw = [sum(int(r.stream_raw[i]) for r in ress) for i in range(6)]
+    scomp = [sum(int(r.stream_comp[i]) for r in ress) for i in range(6)]
     out = {
         "metric": "encode MB/s (input FASTQ), 150 bp Illumina", "value": round(total_in / dt * a.steps / 1e6, 1), "unit": "MB/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "synthetic 150 bp Phred+33 FASTQ, %.2f GB per GPU (BASELINE.json configs[1]), device-resident, "
-                               "100k-record blocks, quality profile %d" % (in_bytes / 1e9, a.quality_profile),
-                   "bytes_per_gpu": in_bytes, "records_per_gpu": int(res.n_records), "blocks_per_gpu": int(res.n_blocks)},
+        "config": {"workload": workload, "bytes_per_gpu": in_bytes, "records_per_gpu": n_records, "blocks_per_gpu": n_blocks,
+                   "device_batches_per_step": launches_per_step},
         "ratio": round(total_in / total_out, 3),
         "decode_MBps": round(in_bytes / ddt / 1e6, 1), "roundtrip_bit_exact": roundtrip_ok,
         "input_frac_of_hbm_peak": round(total_in / dt * a.steps / 1e9 / (HBM_PEAK_GBS * world), 4),
         "roofline": roof, "kernel_ms": kernels,
         "decode_kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in dkern.items()},
-        "stream_ratio": {n: (round(res.stream_raw[i] / res.stream_comp[i], 3) if res.stream_comp[i] else None)
-                         for i, n in enumerate(fq.STREAM_NAMES)},
+        "stream_ratio": {n: (round(sraw[i] / scomp[i], 3) if scomp[i] else None) for i, n in enumerate(fq.STREAM_NAMES)},
     }
+    if sharded_ok is not None:
+        out["sharded_file_layout_ok"] = sharded_ok
     # ---- supplementary: several batches in flight on separate contexts / streams (what a streaming compressor does).
     # The headline `value` above stays the single-stream figure BASELINE.json's config asks for; kernel times there are
     # undisturbed.  Here the kernels of different batches overlap (tails of one fill with work of the next).
-    if a.inflight > 1 and world == 1:
+    if a.inflight > 1 and world == 1 and len(batches) == 1:
         try:
             nc = a.inflight
+            d_text, d_out, text_np = d_texts[0], d_outs[0], batches[0]
             pctx = [fq.Ctx(local_rank) for _ in range(nc)]
             pouts = [torch.empty_like(d_out) for _ in range(nc)]
             pstreams = [torch.cuda.Stream(dev) for _ in range(nc)]
@@ -249,7 +315,7 @@ def main():
                     busy[i] = False
 
             def p_launch(i):
-                fq._lib.check(lib().fqz_encode_batch_launch(pctx[i].handle, d_text.data_ptr(), text_np.size, fq.DEFAULT_BLOCK_SIZE, fq.ENCODING_PHRED33,
+                fq._lib.check(lib().fqz_encode_batch_launch(pctx[i].handle, d_text.data_ptr(), text_np.size, RPB, fq.ENCODING_PHRED33,
                                                             fq.BATCH_FINAL, pouts[i].data_ptr(), pouts[i].numel(), C.c_void_p(pstreams[i].cuda_stream)))
                 busy[i] = True
 
@@ -272,7 +338,7 @@ def main():
             out["pipelined"] = {"error": repr(e)}
     if not a.no_cpu and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(text_np)
+            out["cpu_baseline"] = cpu_baseline(batches[0])
         except Exception as e:  # the baseline leg must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     else:

@@ -733,14 +733,15 @@ __global__ __launch_bounds__(256) void k_dec_index(const uint8_t *in, DecInfo *i
 
 // Content checksums: four lanes per frame, 16 frames per wave; a mismatch fails the decode (the reference's decoder
 // verifies them too: zstd.Decoder defaults, compress.go:120-122).
+#define DXXH_PER_WAVE 16u // frames per wave: every lane busy; 16 stripes in flight per lane cover the latency
 __global__ __launch_bounds__(64) void k_dec_xxh(const uint8_t *in, DecInfo *info, const DecFrame *frames, uint32_t n_frames, const uint8_t *arena, uint32_t stream_mask)
 {
     if (info->status) return;
-    const uint32_t lane = threadIdx.x, f = blockIdx.x * 16 + (lane >> 2);
+    const uint32_t lane = threadIdx.x, f = blockIdx.x * DXXH_PER_WAVE + (lane >> 2);
     DecFrame fr;
     fr.dst_off = fr.len = fr.ck_off = fr.stream = 0;
-    if (f < n_frames) fr = frames[f];
-    const bool on = f < n_frames && fr.ck_off && ((stream_mask >> fr.stream) & 1u);
+    if (f < n_frames && (lane >> 2) < DXXH_PER_WAVE) fr = frames[f];
+    const bool on = f < n_frames && (lane >> 2) < DXXH_PER_WAVE && fr.ck_off && ((stream_mask >> fr.stream) & 1u);
     const unsigned long long h = xxh64_quad(arena + fr.dst_off, on ? fr.len : 0u, lane);
     if (on && (lane & 3) == 0 && (uint32_t)h != rd32(in + fr.ck_off)) dec_fail(info, FQZ_E_CHECKSUM);
 }
@@ -1338,11 +1339,25 @@ __global__ __launch_bounds__(256) void k_dec_sizes(const uint8_t *arena, DecInfo
     uint32_t n_rec = info->n_rec, nb = info->n_blocks;
     if (info->status) return;
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t r0 = blockIdx.x * 256; r0 < n_rec; r0 += gridDim.x * 256) {
+    // a workgroup takes a contiguous run of records (almost always inside one block): the 64-bit block totals are kept in
+    // registers and flushed with one atomic per wave when the block changes and at the end (an atomic per wave and trip on the
+    // three words of a block took 0.4 ms)
+    const uint32_t per = ((n_rec + gridDim.x - 1) / gridDim.x + 255) & ~255u, r_begin = blockIdx.x * per;
+    const uint32_t r_end = r_begin + per < n_rec ? r_begin + per : n_rec;
+    unsigned long long a0 = 0, a1 = 0, a2 = 0; // this lane's share of the totals of block `cur`
+    uint32_t cur = 0xFFFFFFFFu;                // (wave-uniform)
+    auto flush = [&]() {
+        if (cur == 0xFFFFFFFFu) return;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { a0 += __shfl_xor(a0, d, WAVE); a1 += __shfl_xor(a1, d, WAVE); a2 += __shfl_xor(a2, d, WAVE); }
+        if (lane == 0 && (a0 | a1 | a2)) { atomicAdd(&btot[3ull * cur], a0); atomicAdd(&btot[3ull * cur + 1], a1); atomicAdd(&btot[3ull * cur + 2], a2); }
+        a0 = a1 = a2 = 0;
+    };
+    for (uint32_t r0 = r_begin; r0 < r_end; r0 += 256) {
         const uint32_t r = r0 + threadIdx.x;
         unsigned long long v0 = 0, v1 = 0, v2 = 0;
         uint32_t bi = 0xFFFFFFFFu;
-        if (r < n_rec) {
+        if (r < r_end) {
             bi = find_block(blocks, nb, r);
             const DecBlock *b = &blocks[bi];
             uint32_t lr = r - b->rec_base;
@@ -1360,21 +1375,36 @@ __global__ __launch_bounds__(256) void k_dec_sizes(const uint8_t *arena, DecInfo
                 cols[2 * (size_t)cstride + r] = (uint32_t)v2;
             }
         }
-        // block totals: one atomic per wave when the wave's records share a block (almost always)
-        const uint32_t b_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)bi);
-        if (__ballot(bi != b_first) == 0) {
-            if (b_first != 0xFFFFFFFFu) {
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) { v0 += __shfl_xor(v0, d, WAVE); v1 += __shfl_xor(v1, d, WAVE); v2 += __shfl_xor(v2, d, WAVE); }
-                if (lane == 0) { atomicAdd(&btot[3ull * b_first], v0); atomicAdd(&btot[3ull * b_first + 1], v1); atomicAdd(&btot[3ull * b_first + 2], v2); }
-            }
+        // the wave's records share a block almost always; a wave that straddles two blocks adds its lanes one by one
+        const unsigned long long act = __ballot(bi != 0xFFFFFFFFu);
+        if (!act) continue;
+        const uint32_t b_first = (uint32_t)__shfl((int)bi, __ffsll((long long)act) - 1, WAVE);
+        if (__ballot(bi != 0xFFFFFFFFu && bi != b_first) == 0) {
+            if (b_first != cur) { flush(); cur = b_first; }
+            a0 += v0; a1 += v1; a2 += v2;
         } else if (bi != 0xFFFFFFFFu) {
             atomicAdd(&btot[3ull * bi], v0); atomicAdd(&btot[3ull * bi + 1], v1); atomicAdd(&btot[3ull * bi + 2], v2);
         }
     }
+    // the end of the run: the four waves usually hold the same block - one atomic per workgroup and column
+    __shared__ unsigned long long s_part[4][3];
+    __shared__ uint32_t s_cur[4];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a0 += __shfl_xor(a0, d, WAVE); a1 += __shfl_xor(a1, d, WAVE); a2 += __shfl_xor(a2, d, WAVE); }
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane == 0) { s_part[wv][0] = a0; s_part[wv][1] = a1; s_part[wv][2] = a2; s_cur[wv] = cur; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 0; w < 4; w++) {
+            if (s_cur[w] == 0xFFFFFFFFu) continue;
+            unsigned long long t0 = s_part[w][0], t1 = s_part[w][1], t2 = s_part[w][2];
+            for (uint32_t w2 = w + 1; w2 < 4; w2++)
+                if (s_cur[w2] == s_cur[w]) { t0 += s_part[w2][0]; t1 += s_part[w2][1]; t2 += s_part[w2][2]; s_cur[w2] = 0xFFFFFFFFu; }
+            if (t0 | t1 | t2) { atomicAdd(&btot[3ull * s_cur[w]], t0); atomicAdd(&btot[3ull * s_cur[w] + 1], t1); atomicAdd(&btot[3ull * s_cur[w] + 2], t2); }
+        }
+    }
 }
 
-// block totals vs stream lengths: the truncation errors of appendSequence / appendQuality
 // one workgroup: the 64-bit totals of every block against its stream lengths, their sum against the output capacity
 __global__ __launch_bounds__(256) void k_dec_check(DecInfo *info, const DecBlock *blocks, const unsigned long long *btot, size_t out_cap)
 {
@@ -1783,8 +1813,8 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         PROF(ctx, d.side, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, d.side, d_in, info, dch, darena, dbg, late));
         PROF(ctx, d.side, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, d.side, d_in, info, dch, darena, late));
         if (n_frames) { // content checksums of the decoded frames: beside the walks / on the side stream, like the decodes they check
-            PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + 15) / 16), dim3(64), 0, st, d_in, info, dfr, n_frames, darena, early));
-            PROF(ctx, d.side, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + 15) / 16), dim3(64), 0, d.side, d_in, info, dfr, n_frames, darena, late));
+            PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, st, d_in, info, dfr, n_frames, darena, early));
+            PROF(ctx, d.side, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, d.side, d_in, info, dfr, n_frames, darena, late));
         }
         HIP_TRY(hipEventRecord(d.ev_join, d.side));
         forked = true;
@@ -1797,8 +1827,8 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         PROF(ctx, st, "k_dec_walk3", hipLaunchKernelGGL(k_dec_walk3, dim3(n_tiles), dim3(64), 0, st, darena, info, blocks, n_tiles, walkE, offs, ostride));
     }
     if (n_rec) {
-        uint32_t g = (n_rec + 255) / 256;
-        if (g > 4096) g = 4096;
+        uint32_t g = (n_rec + 1023) / 1024; // (runs of >= 1024 records: one flush of the block totals per workgroup)
+        if (g > 2048) g = 2048;
         PROF(ctx, st, "k_dec_sizes", hipLaunchKernelGGL(k_dec_sizes, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride, btot));
     }
     {
@@ -1903,7 +1933,7 @@ int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     if (nch) {
         PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((nch + HG - 1) / HG), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0, 0x3Fu));
         PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(nch), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0x3Fu));
-        if (nfr) PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((nfr + 15) / 16), dim3(64), 0, st, d_src, info, d.frames.as<DecFrame>(), nfr, d_dst, 0x3Fu));
+        if (nfr) PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((nfr + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, st, d_src, info, d.frames.as<DecFrame>(), nfr, d_dst, 0x3Fu));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hi, info, sizeof z, hipMemcpyDeviceToHost, st));

@@ -868,10 +868,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 }
 
 // Content checksum of every frame (= group): four lanes per group, 16 groups per wave (fqz_xxh.h).  xsum[first chunk] = low 32 bits.
+#define XXH_PER_WAVE 16u // groups per wave: every lane busy (the chip is bound by instruction issue); the latency of the chain is covered by 16 stripes in flight per lane
 __global__ __launch_bounds__(64) void k_xxh(const EncInfo *info, const uint4 *xmap, const uint8_t *arena, const uint8_t *npos_arena, uint32_t *xsum)
 {
-    const uint32_t lane = threadIdx.x, g = blockIdx.x * 16 + (lane >> 2);
-    const bool on = g < info->n_xgroups;
+    const uint32_t lane = threadIdx.x, g = blockIdx.x * XXH_PER_WAVE + (lane >> 2);
+    const bool on = g < info->n_xgroups && (lane >> 2) < XXH_PER_WAVE;
     uint4 gd = make_uint4(0, 0, 0, 0);
     if (on) gd = xmap[g];
     const uint32_t s = gd.z >> 28;
@@ -1224,10 +1225,21 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     uint32_t *xsum = (uint32_t *)(e.xmap.as<uint4>() + group_cap);
     PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), e.xmap.as<uint4>(), group_cap,
                                                     csize + e.chunk_cap + 2, csize));
+    // the content checksums need the streams only: they are hashed on a side stream beside the entropy coder (a chain of
+    // memory round trips with a few waves per CU beside a kernel bound by instruction issue) and joined before k_compact
+    if (!e.side) {
+        HIP_TRY(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e.ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(e.ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(e.side, e.ev_fork, 0));
+    PROF(ctx, e.side, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, e.side, info, e.xmap.as<uint4>(), arena, npos, xsum));
+    HIP_TRY(hipEventRecord(e.ev_join, e.side));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
-    PROF(ctx, st, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + 15) / 16), dim3(64), 0, st, info, e.xmap.as<uint4>(), arena, npos, xsum));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
+    HIP_TRY(hipStreamWaitEvent(st, e.ev_join, 0));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, xsum, arena, d_out, (uint32_t)S_SEQ));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
@@ -1340,7 +1352,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     uint32_t *xsum = (uint32_t *)(e.xmap.as<uint4>() + group_cap);
     hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), e.xmap.as<uint4>(), group_cap, csize + chunks + 2, csize);
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
-    PROF(ctx, st, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + 15) / 16), dim3(64), 0, st, info, e.xmap.as<uint4>(), d_src, d_src, xsum));
+    PROF(ctx, st, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, st, info, e.xmap.as<uint4>(), d_src, d_src, xsum));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_dst, cap);
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks ? chunks : 1), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, csize + chunks + 2, xsum, d_src, d_dst, (uint32_t)S_SEQ));

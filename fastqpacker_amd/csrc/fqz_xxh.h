@@ -33,7 +33,16 @@ __device__ __forceinline__ unsigned long long xxh64_quad(const uint8_t *p, uint3
         const uint32_t stripes = len >> 5;
         const uint8_t *s = p + 8 * q;
         uint32_t i = 0;
-        // four stripes per trip: the four loads are in flight together (a stripe step is ~20 dependent ALU operations)
+        // sixteen stripes per trip: the kernel is a chain of memory round trips (a handful of waves per CU, every trip waits
+        // for its loads), so the loads of 512 bytes per quad are in flight together
+        for (; i + 16 <= stripes; i += 16) {
+            unsigned long long x[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = xx_read64(s + 32 * k);
+#pragma unroll
+            for (int k = 0; k < 16; k++) v = xx_round(v, x[k]);
+            s += 512;
+        }
         for (; i + 4 <= stripes; i += 4) {
             const unsigned long long a = xx_read64(s), b = xx_read64(s + 32), c = xx_read64(s + 64), d = xx_read64(s + 96);
             v = xx_round(v, a); v = xx_round(v, b); v = xx_round(v, c); v = xx_round(v, d);

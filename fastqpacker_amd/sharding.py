@@ -35,6 +35,19 @@ def block_offsets_allgather(local_block_lens, max_blocks, device=None, group=Non
     return excl[start:start + n].tolist(), int(flat.sum().item()) + FILE_HEADER_SIZE, allsz
 
 
+def broadcast_encoding(encoding, src=0, device=None, group=None):
+    """The quality encoding is a property of the FILE: the reference detects it once, on the first batch, and writes one
+    FlagPhred64 for all blocks (compress.go:146-164).  Rank `src` (the rank that encodes block 0) detects it
+    (qual_encoding = FQZ_DETECT_ENCODING on its first batch, result in fqz_batch_result.qual_encoding); every other rank
+    passes the broadcast value explicitly.  A shard that detected for itself could normalise with another offset than
+    the file header states, and the file would decode to wrong qualities without any error."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return int(encoding)
+    t = torch.tensor([int(encoding)], dtype=torch.int32, device=device)
+    dist.broadcast(t, src=src, group=group)
+    return int(t.item())
+
+
 def shard_records(total_records, records_per_block, rank, world):
     """Contiguous block ranges per rank: returns (first_record, n_records) for `rank`."""
     n_blocks = (total_records + records_per_block - 1) // records_per_block

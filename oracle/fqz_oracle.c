@@ -552,7 +552,7 @@ static int resolve_workers(int w)
 
 long fqzo_compress(const uint8_t *fastq, size_t n, uint8_t *out, size_t cap, const fqzo_options *opt)
 {
-    fqzo_options o = {0, 0, 0, 0};
+    fqzo_options o = {0, 0, 0, 0, 0};
     if (opt) o = *opt;
     if (!o.block_size) o.block_size = 100000;       /* compress.go:126-131 */
     if (!o.batch_records) o.batch_records = 100000; /* compress.go:48-52: batches are always 100 000 records (App. B-4) */
@@ -588,6 +588,8 @@ long fqzo_compress(const uint8_t *fastq, size_t n, uint8_t *out, size_t cap, con
             }
         if (!below59 && min != 255 && min >= 64) enc = FQZO_PHRED64;
     }
+    if (o.force_encoding == 1) enc = FQZO_PHRED33;
+    if (o.force_encoding == 2) enc = FQZO_PHRED64;
 
     /* compress.go:157-168 */
     if (cap < 10) { free(recs); return FQZO_E_DST_SMALL; }

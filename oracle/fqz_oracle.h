@@ -183,7 +183,9 @@ typedef struct {
     uint32_t block_size;    /* Options.BlockSize (compress.go:75); 0 -> 100000 */
     int workers;            /* Options.Workers (compress.go:76); 0 -> all cores */
     uint32_t batch_records; /* records per block; 0 -> 100000 (batchPool, compress.go:48-52) */
-    int entropy;            /* 0 = FQZ-H1 Huffman frames; 1 = system libzstd level 1 via dlopen (CPU-baseline leg) */
+    int entropy;            /* 0 = FQZ-H2 frames (Huffman literals); 1 = system libzstd level 1 via dlopen (CPU-baseline leg) */
+    int force_encoding;     /* 0 = DetectEncoding on the first batch (compress.go:146-154); 1 = Phred+33, 2 = Phred+64: a shard of a
+                             * file whose first batch another process saw (multi-GPU sharding: rank 0 detects and broadcasts) */
 } fqzo_options;
 
 size_t fqzo_compress_bound(size_t n_bytes);

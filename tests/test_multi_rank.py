@@ -27,13 +27,20 @@ def _worker(rank, world, port, text, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from fastqpacker_amd.sharding import block_offsets_allgather, shard_records
+    from fastqpacker_amd.sharding import block_offsets_allgather, shard_records, broadcast_encoding
     recs, n = O.parse_all(text)
     r0, cnt = shard_records(n, RPB, rank, world)
     start = recs[r0].hdr_off - 1 if cnt else len(text)
     end = (recs[r0 + cnt].hdr_off - 1) if r0 + cnt < n else len(text)
     shard = text[start:end]
-    fqz = O.compress(shard, batch_records=RPB)[10:] if cnt else b""
+    # the encoding is the file's: rank 0 (block 0) detects it, the others take the broadcast value instead of detecting on
+    # their own shard (shard 1 of the test text holds only qualities >= '@' and would pick Phred+64 for itself)
+    mine = 0
+    if rank == 0:
+        quals = [shard[r.qual_off:r.qual_off + r.qual_len] for r in O.parse_all(shard)[0][:RPB]]
+        mine = O.detect_encoding(quals)
+    enc = broadcast_encoding(mine, src=0)
+    fqz = O.compress(shard, batch_records=RPB, force_encoding=1 + enc)[10:] if cnt else b""
     # split the shard's body into blocks by walking the headers
     lens, pos = [], 0
     while pos < len(fqz):
@@ -59,7 +66,10 @@ def _worker(rank, world, port, text, out_path):
 
 
 def test_two_rank_offset_exchange(tmp_path):
-    text = make_fastq(430, seed=12, min_len=60, max_len=150, n_frac=0.01)
+    a = make_fastq(250, seed=12, min_len=60, max_len=150, n_frac=0.01)              # shard 0: Phred+33 qualities from '!' up
+    b = make_fastq(180, seed=13, min_len=60, max_len=150, n_frac=0.01, phred=64)    # shard 1: every quality byte >= '@'
+    text = a + b
+    assert O.detect_encoding([q for q in b.split(b"\n")[3::4]]) == 1 and O.compress(text)[9] == 0
     want = O.compress(text, batch_records=RPB)
     path = str(tmp_path / "out.fqz")
     with open(path, "wb") as f:
