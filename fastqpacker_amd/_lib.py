@@ -70,6 +70,8 @@ _lib = None
 # name -> (restype, argtypes); the single source of truth for tests that check the exports
 _u8p = C.POINTER(C.c_uint8)
 _vp = C.c_void_p
+READ_FN = C.CFUNCTYPE(C.c_long, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)   # fqz_read_fn
+WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)   # fqz_write_fn
 SIGNATURES = {
     "fqz_strerror": (C.c_char_p, [C.c_int]),
     "fqz_last_hip_error": (C.c_char_p, []),
@@ -107,6 +109,10 @@ SIGNATURES = {
     "fqz_entropy_decode": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "fqz_compress": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Options)]),
     "fqz_decompress": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(DecompressOptions)]),
+    "fqz_compress_stream": (C.c_int, [_vp, READ_FN, _vp, WRITE_FN, _vp, C.POINTER(Options)]),
+    "fqz_decompress_stream": (C.c_int, [_vp, READ_FN, _vp, WRITE_FN, _vp, C.POINTER(DecompressOptions)]),
+    "fqz_decompress_alloc": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(DecompressOptions)]),
+    "fqz_buffer_free": (None, [_vp]),
     "fqz_compress_file": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.POINTER(Options)]),
     "fqz_decompress_file": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.POINTER(DecompressOptions)]),
     "fqz_profile_enable": (C.c_int, [_vp, C.c_int]),

@@ -29,15 +29,60 @@ def Compress(fastq, opts: Options = None, ctx=None) -> bytes:
 
 
 def Decompress(fqz, opts: DecompressOptions = None, ctx=None) -> bytes:
-    """compress.Decompress (compress.go:558): .fqz bytes -> FASTQ bytes."""
+    """compress.Decompress (compress.go:558): .fqz bytes -> FASTQ bytes (one decode; the library allocates the text)."""
     ctx = ctx or default_ctx()
     a = _as_u8(fqz)
     n = C.c_size_t(0)
+    p = C.c_void_p()
     o = C.byref(opts) if opts is not None else None
-    check(lib().fqz_decompress(ctx.handle, a.ctypes.data if a.size else None, a.size, None, 0, C.byref(n), o))
-    out = np.empty(max(n.value, 1), dtype=np.uint8)
-    check(lib().fqz_decompress(ctx.handle, a.ctypes.data, a.size, out.ctypes.data, n.value, C.byref(n), o))
-    return out[: n.value].tobytes()
+    check(lib().fqz_decompress_alloc(ctx.handle, a.ctypes.data if a.size else None, a.size, C.byref(p), C.byref(n), o))
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        lib().fqz_buffer_free(p)
+
+
+def CompressStream(reader, writer, opts: Options = None, ctx=None):
+    """compress.Compress(io.Reader, io.Writer, *Options) (compress.go:125) over file-like objects: streams, memory bounded."""
+    ctx = ctx or default_ctx()
+    rd, wr, err = _callbacks(reader, writer)
+    rc = lib().fqz_compress_stream(ctx.handle, rd, None, wr, None, C.byref(opts) if opts is not None else None)
+    if err:
+        raise err[0]
+    check(rc)
+
+
+def DecompressStream(reader, writer, opts: DecompressOptions = None, ctx=None):
+    """compress.Decompress(io.Reader, io.Writer, *DecompressOptions) (compress.go:558) over file-like objects."""
+    ctx = ctx or default_ctx()
+    rd, wr, err = _callbacks(reader, writer)
+    rc = lib().fqz_decompress_stream(ctx.handle, rd, None, wr, None, C.byref(opts) if opts is not None else None)
+    if err:
+        raise err[0]
+    check(rc)
+
+
+def _callbacks(reader, writer):
+    from ._lib import READ_FN, WRITE_FN
+    err = []
+
+    def _rd(_user, dst, cap):
+        try:
+            b = reader.read(cap)
+            C.memmove(dst, b, len(b))
+            return len(b)
+        except Exception as e:  # noqa: BLE001 - reported to the caller after the C call returns
+            err.append(e)
+            return -1
+
+    def _wr(_user, src, n):
+        try:
+            writer.write(C.string_at(src, n))
+            return 0
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+            return 1
+    return READ_FN(_rd), WRITE_FN(_wr), err
 
 
 def encode_block(fastq, qual_encoding=0, ctx=None):

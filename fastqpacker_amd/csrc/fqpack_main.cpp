@@ -37,55 +37,61 @@ static int fail(const std::string &msg)
     return 1;
 }
 
-static bool read_all(FILE *f, std::vector<uint8_t> &buf)
-{
-    size_t n = 0;
-    buf.resize(1 << 20);
-    for (;;) {
-        if (n == buf.size()) buf.resize(buf.size() * 2);
-        size_t r = fread(buf.data() + n, 1, buf.size() - n, f);
-        n += r;
-        if (!r) break;
+// input side: a buffered FILE, optionally behind zlib's inflate (gzip members may be concatenated); the first two bytes
+// are peeked to detect the gzip magic (cmd/fqpack/main.go:142-174)
+struct Input {
+    FILE *f = nullptr;
+    bool gz = false, gz_end = false, failed = false;
+    std::string err;
+    z_stream zs;
+    std::vector<uint8_t> ibuf;
+    uint8_t peek[2];
+    size_t n_peek = 0, peek_pos = 0;
+    size_t raw_read(uint8_t *dst, size_t cap)
+    {
+        size_t got = 0;
+        while (peek_pos < n_peek && got < cap) dst[got++] = peek[peek_pos++];
+        if (got < cap) got += fread(dst + got, 1, cap - got, f);
+        return got;
     }
-    buf.resize(n);
-    return !ferror(f);
+};
+
+static long input_read(void *u, uint8_t *dst, size_t cap)
+{
+    Input *in = (Input *)u;
+    if (!in->gz) {
+        size_t r = in->raw_read(dst, cap);
+        if (ferror(in->f)) { in->failed = true; in->err = "read error"; return -1; }
+        return (long)r;
+    }
+    size_t w = 0;
+    while (w < cap && !in->gz_end) {
+        if (!in->zs.avail_in) {
+            size_t r = in->raw_read(in->ibuf.data(), in->ibuf.size());
+            if (ferror(in->f)) { in->failed = true; in->err = "read error"; return -1; }
+            in->zs.next_in = in->ibuf.data();
+            in->zs.avail_in = (uInt)r;
+            if (!r) { in->failed = true; in->err = "gzip: unexpected EOF"; return -1; }
+        }
+        in->zs.next_out = dst + w;
+        in->zs.avail_out = (uInt)(cap - w > (1u << 30) ? (1u << 30) : cap - w);
+        const uInt before = in->zs.avail_out;
+        int rc = inflate(&in->zs, Z_NO_FLUSH);
+        w += before - in->zs.avail_out;
+        if (rc == Z_STREAM_END) { // another member may follow (concatenated gzip files)
+            if (!in->zs.avail_in) {
+                size_t r = in->raw_read(in->ibuf.data(), in->ibuf.size());
+                in->zs.next_in = in->ibuf.data();
+                in->zs.avail_in = (uInt)r;
+            }
+            if (in->zs.avail_in && inflateReset(&in->zs) == Z_OK) continue;
+            in->gz_end = true;
+        } else if (rc != Z_OK && rc != Z_BUF_ERROR) { in->failed = true; in->err = "gzip: invalid input"; return -1; }
+    }
+    return (long)w;
 }
 
-static bool gunzip(const std::vector<uint8_t> &in, std::vector<uint8_t> &out, std::string &err)
-{
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, 15 + 16) != Z_OK) { err = "cannot open gzip input"; return false; }
-    out.resize(in.size() * 4 + (1 << 20));
-    zs.next_in = (Bytef *)in.data();
-    zs.avail_in = (uInt)in.size();
-    size_t w = 0, consumed = 0;
-    for (;;) {
-        if (w == out.size()) out.resize(out.size() * 2);
-        size_t room = out.size() - w;
-        zs.next_out = out.data() + w;
-        zs.avail_out = (uInt)(room > (1u << 30) ? (1u << 30) : room);
-        uInt before_out = zs.avail_out;
-        if (!zs.avail_in && consumed < in.size()) {
-            size_t left = in.size() - consumed;
-            zs.next_in = (Bytef *)in.data() + consumed;
-            zs.avail_in = (uInt)(left > (1u << 30) ? (1u << 30) : left);
-        }
-        uInt before_in = zs.avail_in;
-        int rc = inflate(&zs, Z_NO_FLUSH);
-        w += before_out - zs.avail_out;
-        consumed += before_in - zs.avail_in;
-        if (rc == Z_STREAM_END) {
-            if (consumed < in.size() && inflateReset(&zs) == Z_OK) continue; // concatenated members
-            break;
-        }
-        if (rc != Z_OK && rc != Z_BUF_ERROR) { inflateEnd(&zs); err = "gzip: invalid input"; return false; }
-        if (rc == Z_BUF_ERROR && consumed >= in.size() && zs.avail_out) { inflateEnd(&zs); err = "gzip: unexpected EOF"; return false; }
-    }
-    inflateEnd(&zs);
-    out.resize(w);
-    return true;
-}
+static int output_write(void *u, const uint8_t *src, size_t n) { return fwrite(src, 1, n, (FILE *)u) != n; }
 
 int main(int argc, char **argv)
 {
@@ -120,43 +126,46 @@ int main(int argc, char **argv)
         fin = fopen(in_path.c_str(), "rb");
         if (!fin) return fail("cannot open input: open " + in_path + ": " + strerror(errno));
     }
-    std::vector<uint8_t> in, tmp, out;
-    if (!read_all(fin, in)) return fail("cannot inspect input: read error");
-    if (fin != stdin) fclose(fin);
+    Input in;
+    in.f = fin;
+    setvbuf(fin, nullptr, _IOFBF, 1 << 20);                               // 1 MiB buffered IO (main.go:123-188)
+    in.n_peek = fread(in.peek, 1, 2, fin);
+    if (ferror(fin)) return fail("cannot inspect input: read error");
     if (!decompress) {
         bool gz_name = in_path.size() >= 3 && !strcasecmp(in_path.c_str() + in_path.size() - 3, ".gz");
-        bool gz_magic = in.size() >= 2 && in[0] == 0x1f && in[1] == 0x8b;
+        bool gz_magic = in.n_peek == 2 && in.peek[0] == 0x1f && in.peek[1] == 0x8b;
         if (gz_name || gz_magic) {
-            std::string err;
-            if (!gunzip(in, tmp, err)) return fail(err);
-            in.swap(tmp);
+            memset(&in.zs, 0, sizeof in.zs);
+            if (inflateInit2(&in.zs, 15 + 16) != Z_OK) return fail("cannot open gzip input");
+            in.gz = true;
+            in.ibuf.resize(1 << 20);
         }
-    }
-
-    fqz_ctx *ctx = nullptr;
-    int rc = fqz_ctx_create(0, &ctx);
-    if (rc) return fail(std::string(fqz_strerror(rc)) + " (" + fqz_last_hip_error() + ")");
-    size_t n = 0;
-    if (decompress) {
-        fqz_decompress_options o = {(int32_t)workers};
-        rc = fqz_decompress(ctx, in.data(), in.size(), nullptr, 0, &n, &o);
-        if (!rc) { out.resize(n ? n : 1); rc = fqz_decompress(ctx, in.data(), in.size(), out.data(), n, &n, &o); }
-    } else {
-        fqz_options o = {(uint32_t)block_size, (int32_t)workers};
-        out.resize(fqz_encode_bound(in.size()) + FQZ_FILE_HEADER_SIZE);
-        rc = fqz_compress(ctx, in.data(), in.size(), out.data(), out.size(), &n, &o);
-    }
-    fqz_ctx_destroy(ctx);
-    if (rc) {
-        const char *ctxmsg = decompress ? "" : (rc <= FQZ_E_HDR_AT && rc >= FQZ_E_LEN_MISMATCH ? "parsing FASTQ: " : "");
-        return fail(std::string(ctxmsg) + fqz_strerror(rc));
     }
     FILE *fout = stdout;
     if (!(out_path.empty() || out_path == "-" || to_stdout)) {
         fout = fopen(out_path.c_str(), "wb");
         if (!fout) return fail("cannot create output: open " + out_path + ": " + strerror(errno));
     }
-    if (n && fwrite(out.data(), 1, n, fout) != n) return fail("write error");
+    setvbuf(fout, nullptr, _IOFBF, 1 << 20);
+
+    fqz_ctx *ctx = nullptr;
+    int rc = fqz_ctx_create(0, &ctx);
+    if (rc) return fail(std::string(fqz_strerror(rc)) + " (" + fqz_last_hip_error() + ")");
+    if (decompress) {
+        fqz_decompress_options o = {(int32_t)workers};
+        rc = fqz_decompress_stream(ctx, input_read, &in, output_write, fout, &o);
+    } else {
+        fqz_options o = {(uint32_t)block_size, (int32_t)workers};
+        rc = fqz_compress_stream(ctx, input_read, &in, output_write, fout, &o);
+    }
+    fqz_ctx_destroy(ctx);
+    if (in.gz) inflateEnd(&in.zs);
+    if (fin != stdin) fclose(fin);
+    if (rc) {
+        if (in.failed) return fail(in.err);
+        const char *ctxmsg = decompress ? "" : (rc <= FQZ_E_HDR_AT && rc >= FQZ_E_LEN_MISMATCH ? "parsing FASTQ: " : "");
+        return fail(std::string(ctxmsg) + fqz_strerror(rc));
+    }
     if (fflush(fout)) return fail("write error");
     if (fout != stdout) fclose(fout);
     return 0;

@@ -107,7 +107,11 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     if (d.side) { (void)hipStreamSynchronize(d.side); (void)hipStreamDestroy(d.side); (void)hipEventDestroy(d.ev_fork); (void)hipEventDestroy(d.ev_join); }
     c->prof.collect();
     for (hipEvent_t ev : c->prof.pool) (void)hipEventDestroy(ev);
+    for (fqz_ctx *lane : c->lanes) fqz_ctx_destroy(lane);
+    c->lanes.clear();
+    (void)hipSetDevice(c->device);
     c->d_in.release(); c->d_out.release(); c->h_stage.release();
+    for (int i = 0; i < 3; i++) { c->sl_new[i].release(); c->sl_hin[i].release(); c->sl_hout[i].release(); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -313,9 +317,10 @@ static int decode_staged(fqz_ctx *ctx, const uint8_t *blocks, size_t n, uint8_t 
     // FASTQ text is bounded by the pre-entropy sizes announced in the frames; the decoder sizes its own
     // staging buffer and reports the exact length
     fqz_batch_result res;
+    ctx->dec.skip_assemble = size_only; // the size is known once the lengths / headers / plus streams are decoded and summed: no text is assembled
     rc = fqz_dec_launch(ctx, ctx->d_in.as<uint8_t>(), n, version, qual_encoding, nullptr, 0, ctx->stream);
-    if (rc) return rc;
-    rc = fqz_dec_finish(ctx, &res);
+    if (!rc) rc = fqz_dec_finish(ctx, &res);
+    ctx->dec.skip_assemble = false;
     if (rc) return rc;
     *out_len = res.out_len;
     if (size_only) return FQZ_OK;
@@ -335,145 +340,6 @@ extern "C" int fqz_decode_block_size(fqz_ctx *ctx, const uint8_t *block, size_t 
 {
     if (!ctx || !block || !out_len) return FQZ_E_ARG;
     return decode_staged(ctx, block, n, version, FQZ_ENCODING_PHRED33, nullptr, 0, out_len, true);
-}
-
-// ===========================================================================
-// compress.Compress / compress.Decompress on memory buffers
-// ===========================================================================
-// Largest slice of FASTQ text handed to one device pass.
-static const size_t FQZ_HOST_BATCH = 512ull << 20;
-
-extern "C" int fqz_compress(fqz_ctx *ctx, const uint8_t *fastq, size_t n, uint8_t *out, size_t out_cap, size_t *out_len,
-                            const fqz_options *opts)
-{
-    if (!ctx || (!fastq && n) || !out || !out_len) return FQZ_E_ARG;
-    *out_len = 0;
-    fqz_options o = {FQZ_DEFAULT_BLOCK_SIZE, 0};                       // compress.go:126-128 (nil opts)
-    if (opts) o = *opts;
-    if (!o.block_size) o.block_size = FQZ_DEFAULT_BLOCK_SIZE;          // compress.go:129-131
-    const uint32_t rpb = FQZ_DEFAULT_BLOCK_SIZE;                       // batches are always 100 000 records (compress.go:48-52, App. B-4)
-    if (out_cap < FQZ_FILE_HEADER_SIZE) return FQZ_E_DST_SMALL;
-    size_t w = FQZ_FILE_HEADER_SIZE, pos = 0;
-    int enc = FQZ_DETECT_ENCODING;                                      // decided on the first batch (compress.go:146-154)
-    bool first = true;
-    uint8_t flags = 0;
-    while (first || pos < n) {
-        size_t take = n - pos < FQZ_HOST_BATCH ? n - pos : FQZ_HOST_BATCH;
-        bool final_batch = pos + take == n;
-        fqz_batch_result res;
-        int rc = encode_staged(ctx, fastq + pos, take, rpb, enc, final_batch ? FQZ_BATCH_FINAL : 0, &res, nullptr, nullptr);
-        if (rc) return rc;                                              // "parsing FASTQ: ..." / "compressing block: ..."
-        if (first) {
-            enc = res.qual_encoding;
-            if (enc == FQZ_ENCODING_PHRED64) flags |= FQZ_FLAG_PHRED64; // compress.go:162-164
-            first = false;
-        }
-        if (!final_batch && res.consumed == 0) {
-            // less than one whole block in this slice: widen it (or finish if it already is everything)
-            return FQZ_E_TOO_LARGE;
-        }
-        if (w + res.out_len > out_cap) return FQZ_E_DST_SMALL;
-        if (res.out_len) HIP_TRY(hipMemcpy(out + w, ctx->d_out.p, res.out_len, hipMemcpyDeviceToHost));
-        w += res.out_len;
-        pos += final_batch ? take : res.consumed;
-        if (final_batch) break;
-    }
-    fqz_file_header fh = {FQZ_VERSION2, o.block_size, flags};          // compress.go:157-161
-    fqz_write_file_header(&fh, out);
-    *out_len = w;
-    return FQZ_OK;
-}
-
-extern "C" int fqz_decompress(fqz_ctx *ctx, const uint8_t *fqz, size_t n, uint8_t *out, size_t out_cap, size_t *out_len,
-                              const fqz_decompress_options *opts)
-{
-    (void)opts;
-    if (!ctx || !fqz || !out_len) return FQZ_E_ARG;
-    *out_len = 0;
-    fqz_file_header fh;
-    int rc = fqz_read_file_header(fqz, n, &fh);                         // compress.go:567-570
-    if (rc) return rc;
-    if (fh.version != FQZ_VERSION1 && fh.version != FQZ_VERSION2) return FQZ_E_FILE_VERSION; // compress.go:571-573
-    int enc = (fh.flags & FQZ_FLAG_PHRED64) ? FQZ_ENCODING_PHRED64 : FQZ_ENCODING_PHRED33;    // compress.go:576-579
-    // walk the block headers (readNextDecompressJob, compress.go:721-758) and cut slices of whole blocks
-    size_t pos = FQZ_FILE_HEADER_SIZE, w = 0;
-    while (pos < n) {
-        size_t start = pos, slice = 0;
-        while (pos < n) {
-            fqz_block_header bh;
-            int hs = fqz_read_block_header(fqz + pos, n - pos, fh.version, &bh);
-            if (hs < 0) return hs;                                      // "reading block header: unexpected EOF"
-            unsigned long long payload = (unsigned long long)bh.seq_size + bh.qual_size + bh.header_size + bh.plus_size +
-                                         bh.npos_size + bh.lengths_size;
-            if (payload > n - pos - (size_t)hs) return FQZ_E_READ_DATA; // compress.go:732
-            size_t blk = (size_t)hs + (size_t)payload;
-            if (slice && slice + blk > FQZ_HOST_BATCH / 2) break;
-            slice += blk;
-            pos += blk;
-        }
-        size_t got = 0;
-        rc = decode_staged(ctx, fqz + start, slice, fh.version, enc, out ? out + w : nullptr, out ? out_cap - w : 0, &got, out == nullptr);
-        if (rc) return rc;
-        w += got;
-    }
-    *out_len = w;
-    return FQZ_OK;
-}
-
-// ---- file forms (cmd/fqpack/main.go:190-203 execute) -----------------------------------
-static int read_file(const char *path, std::vector<uint8_t> &buf)
-{
-    FILE *f = strcmp(path, "-") ? fopen(path, "rb") : stdin;
-    if (!f) return FQZ_E_IO;
-    size_t cap = 1 << 20, n = 0;
-    buf.resize(cap);
-    for (;;) {
-        if (n == cap) { cap *= 2; buf.resize(cap); }
-        size_t r = fread(buf.data() + n, 1, cap - n, f);
-        n += r;
-        if (r == 0) break;
-    }
-    int err = ferror(f);
-    if (f != stdin) fclose(f);
-    buf.resize(n);
-    return err ? FQZ_E_IO : FQZ_OK;
-}
-static int write_file(const char *path, const uint8_t *p, size_t n)
-{
-    FILE *f = strcmp(path, "-") ? fopen(path, "wb") : stdout;
-    if (!f) return FQZ_E_IO;
-    size_t w = n ? fwrite(p, 1, n, f) : 0;
-    int bad = (w != n) || fflush(f);
-    if (f != stdout) bad |= fclose(f);
-    return bad ? FQZ_E_IO : FQZ_OK;
-}
-
-extern "C" int fqz_compress_file(fqz_ctx *ctx, const char *in_path, const char *out_path, const fqz_options *opts)
-{
-    if (!ctx || !in_path || !out_path) return FQZ_E_ARG;
-    std::vector<uint8_t> in, out;
-    int rc = read_file(in_path, in);
-    if (rc) return rc;
-    out.resize(fqz_encode_bound(in.size()) + FQZ_FILE_HEADER_SIZE);
-    size_t n = 0;
-    rc = fqz_compress(ctx, in.data(), in.size(), out.data(), out.size(), &n, opts);
-    if (rc) return rc;
-    return write_file(out_path, out.data(), n);
-}
-
-extern "C" int fqz_decompress_file(fqz_ctx *ctx, const char *in_path, const char *out_path, const fqz_decompress_options *opts)
-{
-    if (!ctx || !in_path || !out_path) return FQZ_E_ARG;
-    std::vector<uint8_t> in, out;
-    int rc = read_file(in_path, in);
-    if (rc) return rc;
-    size_t n = 0;
-    rc = fqz_decompress(ctx, in.data(), in.size(), nullptr, 0, &n, opts);
-    if (rc) return rc;
-    out.resize(n ? n : 1);
-    rc = fqz_decompress(ctx, in.data(), in.size(), out.data(), n, &n, opts);
-    if (rc) return rc;
-    return write_file(out_path, out.data(), n);
 }
 
 // ===========================================================================

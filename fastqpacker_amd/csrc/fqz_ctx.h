@@ -110,6 +110,7 @@ struct DecState {
     uint8_t *user_out = nullptr;
     size_t user_cap = 0;
     bool general = false;
+    bool skip_assemble = false;            // only the decoded size is wanted (fqz_decode_block_size, fqz_decompress with out == NULL)
 };
 
 struct ProfEntry { const char *name; hipEvent_t a, b; };
@@ -169,6 +170,9 @@ struct fqz_ctx {
     // staging for the host-buffer entry points
     DevBuf d_in, d_out;
     PinnedBuf h_stage;
+    DevBuf sl_new[3];             // slices in flight of the streaming pipeline: device side,
+    PinnedBuf sl_hin[3], sl_hout[3]; // pinned staging for callback sources / sinks
+    std::vector<fqz_ctx *> lanes; // child contexts of the streaming pipeline (fqz_stream.hip): own stream and workspaces each
 };
 
 // fqz_encode.hip

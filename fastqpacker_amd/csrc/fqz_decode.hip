@@ -1762,11 +1762,13 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     }
     if (arena > 0xFFFFFFF0ull || chunks > 0x7FFFFFFFull || out_bound > 0xFFFFFFF0ull || tiles > 0x7FFFFFFFull || nframes > 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
     const uint32_t n_tiles = (uint32_t)tiles;
-    if (!d_out) { // host-buffer entry points: decode into the context's staging buffer
+    const bool skip_assemble = d.skip_assemble;
+    if (!d_out && !skip_assemble) { // host-buffer entry points: decode into the context's staging buffer
         if ((rc = ctx->d_out.ensure((size_t)out_bound + 64))) return rc;
         d_out = ctx->d_out.as<uint8_t>();
         out_cap = (size_t)out_bound + 64;
     }
+    if (skip_assemble) out_cap = 0xFFFFFFF0ull; // nothing is written: only the total is reported
     d.d_out = d_out; d.out_cap = out_cap;
     const uint32_t n_chunks = (uint32_t)chunks;
     const uint32_t ostride = n_rec + 1, cstride = n_rec + 1;
@@ -1845,7 +1847,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         if (!g) g = 1;
         uint32_t qoff = qual_encoding == FQZ_ENCODING_PHRED64 ? 64u : 33u;
         if (forked) { HIP_TRY(hipStreamWaitEvent(st, d.ev_join, 0)); forked = false; }
-        PROF(ctx, st, "k_dec_assemble", hipLaunchKernelGGL(k_dec_assemble, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride, qoff, d_out));
+        if (!skip_assemble) PROF(ctx, st, "k_dec_assemble", hipLaunchKernelGGL(k_dec_assemble, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride, qoff, d_out));
     }
     if (forked) HIP_TRY(hipStreamWaitEvent(st, d.ev_join, 0)); // (no records: nothing assembled, still join)
     HIP_TRY(hipGetLastError());

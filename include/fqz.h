@@ -219,7 +219,19 @@ int fqz_compress(fqz_ctx *ctx, const uint8_t *fastq, size_t n, uint8_t *out, siz
 /* compress.Decompress (compress.go:558). out==NULL: only *out_len is computed. */
 int fqz_decompress(fqz_ctx *ctx, const uint8_t *fqz, size_t n, uint8_t *out, size_t out_cap, size_t *out_len,
                    const fqz_decompress_options *opts);
-/* File-to-file forms used by the fqpack CLI driver (cmd/fqpack/main.go:190-203). */
+/* The reference's own shape: compress.Compress(io.Reader, io.Writer, *Options) compress.go:125 and
+ * compress.Decompress(io.Reader, io.Writer, *DecompressOptions) :558.  read returns the bytes it put into dst
+ * (0 = end of input, < 0 = error), write returns 0 on success.  Streaming: three slices are in flight (H2D of the next,
+ * kernels of this one, D2H of the previous one); memory use does not grow with the input. */
+typedef long (*fqz_read_fn)(void *user, uint8_t *dst, size_t cap);
+typedef int (*fqz_write_fn)(void *user, const uint8_t *src, size_t n);
+int fqz_compress_stream(fqz_ctx *ctx, fqz_read_fn read, void *read_user, fqz_write_fn write, void *write_user, const fqz_options *opts);
+int fqz_decompress_stream(fqz_ctx *ctx, fqz_read_fn read, void *read_user, fqz_write_fn write, void *write_user,
+                          const fqz_decompress_options *opts);
+/* compress.Decompress into a buffer the library allocates (one decode, no sizing pass); release it with fqz_buffer_free. */
+int fqz_decompress_alloc(fqz_ctx *ctx, const uint8_t *fqz, size_t n, uint8_t **out, size_t *out_len, const fqz_decompress_options *opts);
+void fqz_buffer_free(uint8_t *p);
+/* File-to-file forms used by the fqpack CLI driver (cmd/fqpack/main.go:190-203); stream through the same pipeline. */
 int fqz_compress_file(fqz_ctx *ctx, const char *in_path, const char *out_path, const fqz_options *opts);
 int fqz_decompress_file(fqz_ctx *ctx, const char *in_path, const char *out_path, const fqz_decompress_options *opts);
 

@@ -1,0 +1,130 @@
+"""The streaming host pipeline (compress.Compress / compress.Decompress over readers and writers, compress.go:125-192,
+558-604): many batches through small slices, blocks that do not fit a slice (long reads), file forms, bounded memory."""
+import io
+import os
+import resource
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fastq_gen import make_fastq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fq():
+    import fastqpacker_amd as fq
+    fq.lib()
+    return fq
+
+
+@pytest.fixture()
+def small_slices(monkeypatch):
+    monkeypatch.setenv("FQZ_SLICE_KB", "256")   # 256 KiB slices: a 100 000-record block spans many of them
+    yield
+
+
+def test_many_slices_give_the_same_file(fq, small_slices):
+    text = make_fastq(120_000, seed=31, min_len=60, max_len=120, n_frac=0.01)   # > 1 block of 100 000 records, ~100 slices
+    want = O.compress(text, workers=8)
+    assert fq.compress.Compress(text) == want                                   # memory -> memory through the three-slot pipeline
+    src, dst = io.BytesIO(text), io.BytesIO()
+    fq.compress.CompressStream(src, dst)                                        # reader -> writer
+    assert dst.getvalue() == want
+    back = io.BytesIO()
+    fq.compress.DecompressStream(io.BytesIO(want), back)
+    assert back.getvalue() == text
+    assert fq.compress.Decompress(want) == text
+
+
+def test_blocks_larger_than_a_slice_long_reads(fq, small_slices):
+    """records of several KB - the first 100 000 records do not fit one slice; the batch grows instead of
+    failing with FQZ_E_TOO_LARGE."""
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(300):
+        L = int(rng.integers(3000, 9000))
+        seq = bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8))
+        qual = bytes(rng.integers(35, 70, L).astype(np.uint8))
+        recs.append(b"@ont_read_%d ch=%d\n%s\n+\n%s\n" % (i, i % 512, seq, qual))
+    text = b"".join(recs)
+    assert len(text) > 6 * (256 << 10)
+    z = fq.compress.Compress(text)
+    assert z == O.compress(text)
+    assert fq.compress.Decompress(z) == text
+
+
+def test_file_forms_stream_and_errors(fq, tmp_path, small_slices):
+    import ctypes as C
+    from fastqpacker_amd._lib import lib, check, default_ctx
+    text = make_fastq(30_000, seed=9, min_len=80, max_len=151, n_frac=0.02, phred=64)
+    a, b, c = tmp_path / "in.fq", tmp_path / "out.fqz", tmp_path / "back.fq"
+    a.write_bytes(text)
+    ctx = default_ctx()
+    check(lib().fqz_compress_file(ctx.handle, str(a).encode(), str(b).encode(), None))
+    assert b.read_bytes() == O.compress(text)
+    check(lib().fqz_decompress_file(ctx.handle, str(b).encode(), str(c).encode(), None))
+    assert c.read_bytes() == text
+    # size-only decompress (out == NULL) and a too-small destination
+    z = b.read_bytes()
+    zin = np.frombuffer(z, dtype=np.uint8)
+    n = C.c_size_t(0)
+    check(lib().fqz_decompress(ctx.handle, zin.ctypes.data, zin.size, None, 0, C.byref(n), None))
+    assert n.value == len(text)
+    small = np.empty(len(text) - 1, dtype=np.uint8)
+    assert lib().fqz_decompress(ctx.handle, zin.ctypes.data, zin.size, small.ctypes.data, small.size, C.byref(n), None) == -18  # FQZ_E_DST_SMALL
+    # a parser error in a late slice still surfaces; partial output is the caller's business (compress.go:165, App. B-9)
+    bad = text[:2_000_000] + b"oops\n" + text[2_000_000:]
+    with pytest.raises(fq.FqzError):
+        fq.compress.Compress(bad)
+    # truncated containers
+    with pytest.raises(fq.FqzError, match="unexpected EOF"):
+        fq.compress.Decompress(z[:-5])
+    # a reader that fails
+    class Broken(io.RawIOBase):
+        def read(self, n=-1):
+            raise OSError("disk on fire")
+    with pytest.raises(OSError):
+        fq.compress.CompressStream(Broken(), io.BytesIO())
+    # the context still works
+    assert fq.compress.Decompress(fq.compress.Compress(text)) == text
+
+
+def test_decode_block_size_does_not_assemble(fq):
+    text = make_fastq(5000, seed=4, min_len=100, max_len=151)
+    block, nrec = fq.compress.encode_block(text)
+    import ctypes as C
+    from fastqpacker_amd._lib import lib, check, default_ctx
+    n = C.c_size_t(0)
+    a = np.frombuffer(block, dtype=np.uint8)
+    check(lib().fqz_decode_block_size(default_ctx().handle, a.ctypes.data, a.size, 2, C.byref(n)))
+    assert n.value == len(text) and nrec == 5000
+
+
+def test_memory_stays_bounded_for_a_large_stream(fq, tmp_path):
+    """A 1.2 GB file through fqz_compress_file / fqz_decompress_file: the process' peak RSS grows by far less than the file."""
+    import ctypes as C
+    from fastqpacker_amd import compress
+    from fastqpacker_amd._lib import lib, check, default_ctx
+    ctx = default_ctx()
+    text, n = compress.synth_fastq(3_400_000)
+    src = tmp_path / "big.fq"
+    text.tofile(str(src))
+    size = text.size
+    del text
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    check(lib().fqz_compress_file(ctx.handle, str(src).encode(), str(tmp_path / "big.fqz").encode(), None))
+    check(lib().fqz_decompress_file(ctx.handle, str(tmp_path / "big.fqz").encode(), str(tmp_path / "big.out").encode(), None))
+    after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert os.path.getsize(tmp_path / "big.out") == size
+    # byte compare in pieces
+    with open(src, "rb") as f, open(tmp_path / "big.out", "rb") as g:
+        while True:
+            x, y = f.read(1 << 26), g.read(1 << 26)
+            assert x == y
+            if not x:
+                break
+    grown_mb = max(0, after - before) / 1024
+    assert grown_mb < 0.5 * size / 1e6, "peak RSS grew by %.0f MB for a %.0f MB file" % (grown_mb, size / 1e6)
