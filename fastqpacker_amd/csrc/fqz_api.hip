@@ -96,7 +96,7 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     EncState &e = c->enc;
-    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.stamps, &e.lf, &e.zstate, &e.scan_state, &e.gmap, &e.xmap};
+    DevBuf *eb[] = {&e.info, &e.tile_cnt, &e.ls, &e.E, &e.plans, &e.arena, &e.npos, &e.slots, &e.csize, &e.stamps, &e.lf, &e.zstate, &e.scan_state, &e.gmap, &e.xmap, &e.hside};
     for (DevBuf *b : eb) b->release();
     e.h_info.release(); e.h_plans.release();
     if (e.side) { (void)hipStreamSynchronize(e.side); (void)hipStreamDestroy(e.side); (void)hipEventDestroy(e.ev_fork); (void)hipEventDestroy(e.ev_join); }
@@ -222,13 +222,13 @@ extern "C" int fqz_encode_batch_dev(fqz_ctx *ctx, const uint8_t *d_fastq, size_t
                                     uint32_t flags, uint8_t *d_out, size_t out_cap, fqz_batch_result *res, uint64_t *block_off,
                                     uint64_t *block_len, size_t max_blocks, void *stream)
 {
-    for (int attempt = 0; attempt < 3; attempt++) {
+    for (int attempt = 0; attempt < 4; attempt++) {
         int rc = fqz_encode_batch_launch(ctx, d_fastq, n_bytes, records_per_block, qual_encoding, flags, d_out, out_cap, stream);
         if (rc) return rc;
         rc = fqz_encode_batch_finish(ctx, res, block_off, block_len, max_blocks);
         // very short lines: a tile-local line slot overflowed (finish() switched the context to the two-pass index) and / or
         // there are more lines than the optimistic line-table capacity (finish() recorded the exact need): run again
-        if (rc == FQZ_E_TOO_LARGE && attempt < 2) continue;
+        if (rc == FQZ_E_TOO_LARGE && attempt < 3) continue;
         return rc;
     }
     return FQZ_E_TOO_LARGE;

@@ -80,6 +80,8 @@ struct EncState {
     DevBuf zstate;    // look-back states and tickets of the batch's scans (zeroed by k_init)
     DevBuf scan_state; // look-back states of k_scan + its ticket
     DevBuf gmap;      // chunk-group descriptors (k_group_map)
+    DevBuf hside;     // headers model: sequences | literals | Sequences_Sections | HdrSide | chunk list (fqz_hdrlz.h)
+    uint32_t hcap = 0, hcap_need = 0; // headers chunks the side buffers hold / the last batch needed
     DevBuf xmap;      // descriptors of every group (frame) for the content checksums | xsum[chunk_cap]
     DevBuf plans;     // BlockPlan[block_cap]
     DevBuf arena;     // seq/qual/hdr/plus/len pre-entropy streams

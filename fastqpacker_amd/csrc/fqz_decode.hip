@@ -33,6 +33,7 @@ struct DecBlock {
     uint32_t indexed[FQZ_NS];       // the payload starts with our index frame (FQZ-H2): its zstd blocks are located without a walk
     uint32_t n_frames[FQZ_NS];      // zstd frames of the payload (content checksums are verified per frame)
     uint32_t frame_base[FQZ_NS];    // first entry of the payload in the frame table
+    uint32_t seq_scratch;           // arena offset of the scratch of the headers stream's blocks with sequences (DSEQ_STRIDE each; 0: none)
 };
 
 struct DecFrame {
@@ -51,7 +52,14 @@ struct DecChunk {
     uint32_t tree_off;  // treeless literals: offset in d_in of the Huffman tree description of the group's first block ...
     uint32_t tree_len;  // ... and the bytes available there (0 = the block carries its own tree)
     uint32_t stream;    // S_SEQ .. S_LEN: which of the block's six payloads (the launches take a stream mask)
+    uint32_t seq_len;   // 0, or the bytes of the block's Sequences_Section (fqz_decode_seq.h): dst_off / regen then describe the
+    uint32_t out_off;   // LITERALS (decoded into a scratch area) and out_off / out_len the block's place in the stream
+    uint32_t out_len;
 };
+
+#define DSEQ_MAX 2048u                                   // sequences per block the fast path takes
+#define DSEQ_STRIDE (2u * FQZ_CHUNK + 64u)               // scratch per block: [literals 16 KiB | triples 16 KiB | nseq u32 ...]
+#define DSEQ_INVALID 0xFFFFFFFFu
 
 __device__ __forceinline__ uint32_t rd32(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 __device__ __forceinline__ uint32_t rd24(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
@@ -245,7 +253,7 @@ __device__ __forceinline__ void frame_win_tail(uint8_t *buf, const uint8_t *in, 
 struct FrameWalk {
     uint32_t pos, nch, dst, in_frame, ck, state; // state: 0 = go on, 1 = done, 2 = failed
     uint32_t nfr, fstart;                         // frames completed, arena offset of the current frame's content
-    uint32_t fcs_lo, fcs_hi, has_fcs, lz;
+    uint32_t fcs_lo, fcs_hi, has_fcs, lz, frame_lz;
     uint32_t tree_off, tree_len; // last Huffman tree description seen in the frame (for treeless blocks)
     uint32_t frame_regen_lo, frame_regen_hi, total_lo, total_hi;
 };
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
             // wave 0, every lane with the same values: the chain of block headers is walked with scalar instructions
             uint32_t pos = UNI(W.pos), nch = UNI(W.nch), dst = UNI(W.dst), in_frame = UNI(W.in_frame), ck = UNI(W.ck), st = 0;
             uint32_t nfr = UNI(W.nfr), fstart = UNI(W.fstart);
-            uint32_t has_fcs = UNI(W.has_fcs), lz = 0, tree_off = UNI(W.tree_off), tree_len = UNI(W.tree_len);
+            uint32_t has_fcs = UNI(W.has_fcs), lz = UNI(W.lz), frame_lz = UNI(W.frame_lz), tree_off = UNI(W.tree_off), tree_len = UNI(W.tree_len);
             unsigned long long fcs = ((unsigned long long)UNI(W.fcs_hi) << 32) | UNI(W.fcs_lo);
             unsigned long long frame_regen = ((unsigned long long)UNI(W.frame_regen_hi) << 32) | UNI(W.frame_regen_lo);
             unsigned long long regen_total = ((unsigned long long)UNI(W.total_hi) << 32) | UNI(W.total_lo);
@@ -330,6 +338,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                     pos += UNI(hdr);
                     frame_regen = 0;
                     in_frame = 1;
+                    frame_lz = 0;
                     tree_len = 0;
                     fstart = dst;
                     continue;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                 const uint32_t n_huf = fmt <= 1 ? 3u : (fmt == 2 ? 4u : 5u);
                 const uint32_t need = lt2 <= 1 ? n_plain : n_huf;
                 const uint32_t csize = type == 1 ? 1u : bs;
-                const uint32_t regen = type == 2 ? (lt2 <= 1 ? r_plain : r_huf) : bs;
+                uint32_t regen = type == 2 ? (lt2 <= 1 ? r_plain : r_huf) : bs;
                 // a block of ours ends right after the literals with Number_of_Sequences = 0; anything longer carries LZ sequences
                 const uint32_t c_huf = fmt <= 1 ? ((lh >> 14) & 0x3FFu) : (fmt == 2 ? ((lh >> 18) & 0x3FFFu) : (((lh >> 22) | ((h1 >> 24) << 10)) & 0x3FFFFu));
                 const uint32_t lit_total = need + (lt2 == 0 ? r_plain : (lt2 == 1 ? 1u : c_huf));
@@ -362,9 +371,12 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                     // foreign frame.  With the speculative sizes that is a wrong guess; on the general path the payload is
                     // handed to k_dec_lz, which needs ONE frame that states its content size
                     if (pass == 2) { st = 3; break; }
-                    if (pass == 0 && has_fcs && regen_total == 0 && fcs <= 0x7FFFFFF0ull) { lz = 1; st = 1; break; }
-                    st = 2;
-                    break;
+                    // general path: the payload is handed to k_dec_lz as a whole.  What a frame with such blocks regenerates is
+                    // only known from its content size, so it has to state one; the walk goes on to add up the frames
+                    if (!(pass == 0 && has_fcs && fcs <= 0x7FFFFFF0ull)) { st = 2; break; }
+                    lz = 1;
+                    frame_lz = 1;
+                    regen = 0;
                 }
                 const bool bad = (n - pos < 3) | (type == 3) | ((type == 2) & ((bs < need) | (bs > 128 * 1024))) | (csize > n - cpos) | (regen > 128 * 1024);
                 if (bad) { st = 2; break; }
@@ -379,6 +391,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                         c.tree_off = (type == 2 && lt2 == 3) ? tree_off : 0;
                         c.tree_len = (type == 2 && lt2 == 3) ? tree_len : 0;
                         c.stream = (uint32_t)s;
+                        c.seq_len = 0; c.out_off = dst; c.out_len = regen;
                         out[nch] = c;
                     }
                     dst += regen;
@@ -389,6 +402,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                 frame_regen += regen;
                 if (last) {
                     if (ck && n - pos < 4) { st = 2; break; }
+                    if (frame_lz) frame_regen = fcs;
                     if (has_fcs && fcs != frame_regen) { st = 2; break; }
                     if (fout && (pass == 1 || nfr < nfr_expected) && t == 0) {
                         DecFrame f;
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                 }
             }
             if (t == 0) {
-                W.pos = pos; W.nch = nch; W.dst = dst; W.in_frame = in_frame; W.ck = ck; W.state = st; W.has_fcs = has_fcs; W.lz = lz; W.tree_off = tree_off; W.tree_len = tree_len;
+                W.pos = pos; W.nch = nch; W.dst = dst; W.in_frame = in_frame; W.ck = ck; W.state = st; W.has_fcs = has_fcs; W.lz = lz; W.frame_lz = frame_lz; W.tree_off = tree_off; W.tree_len = tree_len;
                 W.nfr = nfr; W.fstart = fstart;
                 W.fcs_lo = (uint32_t)fcs; W.fcs_hi = (uint32_t)(fcs >> 32);
                 W.frame_regen_lo = (uint32_t)frame_regen; W.frame_regen_hi = (uint32_t)(frame_regen >> 32);
@@ -420,9 +434,9 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
     if (t == 0) {
         const unsigned long long regen_total = ((unsigned long long)W.total_hi << 32) | W.total_lo;
         if (W.state == 3) { dec_fail(info, FQZ_DEC_RETRY_GENERAL); return; }
-        if (W.lz) { b->raw_len[s] = W.fcs_lo; b->n_chunks[s] = 0; b->n_frames[s] = 0; b->lz[s] = 1; return; }
         if (W.state == 2 || W.in_frame) { dec_fail(info, FQZ_E_ENTROPY); return; }
         if (regen_total > 0x7FFFFFFFull) { dec_fail(info, FQZ_E_TOO_LARGE); return; }
+        if (W.lz) { b->raw_len[s] = (uint32_t)regen_total; b->n_chunks[s] = 0; b->n_frames[s] = 0; b->lz[s] = 1; return; }
         if (!pass) { b->raw_len[s] = (uint32_t)regen_total; b->n_chunks[s] = W.nch; b->n_frames[s] = W.nfr; }
         if (pass == 2 && (W.nch != n_expected || regen_total != b->raw_len[s] || W.nfr != nfr_expected)) dec_fail(info, FQZ_DEC_RETRY_GENERAL);
     }
@@ -629,7 +643,24 @@ __global__ __launch_bounds__(64) void k_dec_lz(const uint8_t *in, DecInfo *info,
     const int s = id % FQZ_NS;
     const uint32_t slot = LZU(b->lz[s]);
     if (!slot) return;
-    const int r = lz_decode_frame(L, in + LZU(b->pay_off[s]), LZU(b->pay_len[s]), arena + LZU(b->a_off[s]), LZU(b->raw_len[s]), scratch + (size_t)(slot - 1) * LZ_SCRATCH);
+    // the frames of the payload one after the other (skippable frames are not content)
+    const uint8_t *p = in + LZU(b->pay_off[s]);
+    const uint32_t n = LZU(b->pay_len[s]), raw = LZU(b->raw_len[s]);
+    uint32_t pos = 0, out = 0;
+    int r = 0;
+    while (pos < n && r >= 0) {
+        if (n - pos >= 8 && LZU(skippable_magic(p + pos))) {
+            const uint32_t ssz = LZU(rd32(p + pos + 4));
+            if (ssz > n - pos - 8) { r = -1; break; }
+            pos += 8 + ssz;
+            continue;
+        }
+        uint32_t used = 0, made = 0;
+        r = lz_decode_frame(L, p + pos, n - pos, arena + LZU(b->a_off[s]) + out, raw - out, scratch + (size_t)(slot - 1) * LZ_SCRATCH, &used, &made);
+        pos += used;
+        out += made;
+    }
+    if (r >= 0 && out != raw) r = -1;
     if (r < 0) dec_fail(info, r == -2 ? FQZ_E_CHECKSUM : FQZ_E_ENTROPY);
 }
 
@@ -677,6 +708,7 @@ __global__ __launch_bounds__(256) void k_dec_index(const uint8_t *in, DecInfo *i
                 DecChunk d;
                 d.src_off = pos + 3; d.csize = csize; d.dst_off = b->a_off[s] + c * FQZ_CHUNK; d.regen = mk; d.btype = type;
                 d.tree_off = 0; d.tree_len = 0; d.stream = (uint32_t)s;
+                d.seq_len = 0; d.out_off = d.dst_off; d.out_len = mk;
                 if (type == 3 || 3 + csize != sz || last != (last_in_group ? 1u : 0u)) bad = true;
                 else if (type != 2) { if (bs != mk) bad = true; }
                 else {
@@ -691,8 +723,13 @@ __global__ __launch_bounds__(256) void k_dec_index(const uint8_t *in, DecInfo *i
                     const uint32_t c_huf = fmt <= 1 ? ((lh >> 14) & 0x3FFu) : (fmt == 2 ? ((lh >> 18) & 0x3FFFu) : (((lh >> 22) | ((uint32_t)q[7] << 10)) & 0x3FFFFu));
                     const uint32_t lit_total = need + (lt2 == 0 ? r_plain : (lt2 == 1 ? 1u : c_huf));
                     const uint32_t regen = lt2 <= 1 ? r_plain : r_huf;
-                    if (bs < need || lit_total + 1 != bs || regen != mk) bad = true;
-                    else if (lt2 == 3) { // treeless: the tree travels with an earlier Compressed block of the group
+                    if (bs >= need && lit_total + 2 <= bs && regen <= mk && s == S_HDR && b->seq_scratch && q[3 + lit_total] != 0) {
+                        // sequences behind the literals (headers model, fqz_decode_seq.h): the literals go to the block's scratch
+                        d.dst_off = b->seq_scratch + c * DSEQ_STRIDE;
+                        d.regen = regen;
+                        d.seq_len = bs - lit_total;
+                    } else if (bs < need || lit_total + 1 != bs || regen != mk) bad = true;
+                    if (!bad && lt2 == 3) { // treeless: the tree travels with an earlier Compressed block of the group
                         uint32_t back = 0; // bytes from that block's header to this one's
                         bool found = false;
                         for (uint32_t j = 1; j <= cg && !found; j++) {
@@ -800,6 +837,8 @@ __device__ __forceinline__ int bbp_init(BackBitsP &b, const uint8_t *p, uint32_t
     return (int)(n - 1) * 8 + highbit32_d(p[n - 1]);
 }
 
+#include "fqz_decode_seq.h"
+
 #define HG 16           // blocks per wave
 #define L1_BITS 8
 #define L1_ESC 0xFFFFu
@@ -834,7 +873,7 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
             if (fmt == 1) { lh = 3; lsize = (rd24(src) >> 14) & 0x3FF; }
             else if (fmt == 2) { lh = 4; lsize = rd32(src) >> 18; }
             else { lh = 5; lsize = (rd32(src) >> 22) | ((uint32_t)src[4] << 10); }
-            ok = (lh + lsize + 1 == c.csize && src[lh + lsize] == 0 && regen >= 4) ? 1u : 0u;
+            ok = (lh + lsize + (c.seq_len ? c.seq_len : 1u) == c.csize && (c.seq_len || src[lh + lsize] == 0) && regen >= 4) ? 1u : 0u;
         }
     }
     if (ok && sub == 0) {
@@ -1060,7 +1099,7 @@ __global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *
     if (type <= 1) {
         lh = (fmt == 0 || fmt == 2) ? 1 : (fmt == 1 ? 2 : 3);
         lsize = type == 0 ? regen : 1;
-        if (lh + lsize + 1 != n || src[lh + lsize] != 0) { dec_fail(info, FQZ_E_ENTROPY); return; }
+        if (lh + lsize + (c.seq_len ? c.seq_len : 1u) != n || (!c.seq_len && src[lh + lsize] != 0)) { dec_fail(info, FQZ_E_ENTROPY); return; }
         if (type == 0) for (uint32_t i = lane; i < regen; i += 64) dst[i] = src[lh + i];
         else { uint8_t v = src[lh]; for (uint32_t i = lane; i < regen; i += 64) dst[i] = v; }
         return;
@@ -1068,7 +1107,7 @@ __global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *
     if (fmt <= 1) { lh = 3; lsize = (rd24(src) >> 14) & 0x3FF; nstreams = fmt ? 4 : 1; }
     else if (fmt == 2) { lh = 4; lsize = rd32(src) >> 18; nstreams = 4; }
     else { lh = 5; lsize = (rd32(src) >> 22) | ((uint32_t)src[4] << 10); nstreams = 4; }
-    if (lh + lsize + 1 != n || src[lh + lsize] != 0) { dec_fail(info, FQZ_E_ENTROPY); return; } // sequences present: unsupported subset
+    if (lh + lsize + (c.seq_len ? c.seq_len : 1u) != n || (!c.seq_len && src[lh + lsize] != 0)) { dec_fail(info, FQZ_E_ENTROPY); return; } // sequences nobody announced
     const uint8_t *ip = src + lh;
     const bool treeless = type == 3; // the table comes from the tree of an earlier block of the frame (DecChunk.tree_off)
     if (treeless && !c.tree_len) { if (lane == 0) dec_fail(info, FQZ_E_ENTROPY); return; }
@@ -1670,7 +1709,8 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
 int fqz_dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t version, int qual_encoding, uint8_t *d_out, size_t out_cap,
                    hipStream_t st)
 {
-    static const bool force_general = getenv("FQZ_DEC_GENERAL") && atoi(getenv("FQZ_DEC_GENERAL")); // test hook
+    const char *fg = getenv("FQZ_DEC_GENERAL"); // test hook (read on every call: tests switch it)
+    const bool force_general = fg && atoi(fg);
     return dec_launch(ctx, d_in, n_bytes, version, qual_encoding, d_out, out_cap, st, force_general);
 }
 
@@ -1751,6 +1791,14 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         }
         out_bound += (unsigned long long)hb[b].raw_len[S_HDR] + hb[b].raw_len[S_PLUS] + 2ull * hb[b].raw_len[S_QUAL] + 4ull * hb[b].nrec;
     }
+    bool any_seq = false; // scratch for the blocks with sequences of our own headers streams (fqz_decode_seq.h), behind the streams
+    for (uint32_t b = 0; b < nb; b++) {
+        hb[b].seq_scratch = 0;
+        if (!hb[b].indexed[S_HDR] || !hb[b].n_chunks[S_HDR]) continue;
+        hb[b].seq_scratch = (uint32_t)arena;
+        arena += (unsigned long long)hb[b].n_chunks[S_HDR] * DSEQ_STRIDE;
+        any_seq = true;
+    }
     // NumRecords comes from the (untrusted) block header: tie it to the decoded stream sizes before anything is sized from it.
     // Order as blockReader.writeRecord meets them (compress.go:944-975): length, N positions, header.
     for (uint32_t b = 0; b < nb; b++) {
@@ -1812,6 +1860,10 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         HIP_TRY(hipStreamWaitEvent(d.side, d.ev_fork, 0));
         PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, st, d_in, info, dch, darena, dbg, early));
         PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, st, d_in, info, dch, darena, early));
+        if (any_seq) { // headers blocks with sequences: their literals are in the scratch now
+            PROF(ctx, st, "k_dec_seq_fse", hipLaunchKernelGGL(k_dec_seq_fse, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_in, info, dch, darena));
+            PROF(ctx, st, "k_dec_seq_exec", hipLaunchKernelGGL(k_dec_seq_exec, dim3(n_chunks), dim3(64), 0, st, info, dch, darena));
+        }
         PROF(ctx, d.side, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, d.side, d_in, info, dch, darena, dbg, late));
         PROF(ctx, d.side, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, d.side, d_in, info, dch, darena, late));
         if (n_frames) { // content checksums of the decoded frames: beside the walks / on the side stream, like the decodes they check

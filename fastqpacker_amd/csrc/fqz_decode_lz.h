@@ -145,15 +145,20 @@ __device__ int lz_seq_table(LzLds &L, int which /*0 LL, 1 OF, 2 ML*/, int mode, 
 
 #define LZU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
-// Decodes one frame `in[p0, p0+n)` with content size `raw` into dst[0, raw).  lit = per-wave scratch (128 KiB).
-// Every lane of the (single-wave) workgroup calls this with the same arguments.  Returns 0 or -1.
-__device__ int lz_decode_frame(LzLds &L, const uint8_t *in, uint32_t n, uint8_t *dst, uint32_t raw, uint8_t *lit)
+// Decodes the frame that starts at `in` (n bytes are there: the frame and whatever follows it) into dst[0, cap); a frame
+// that states its content size must produce exactly that.  lit = per-wave scratch (128 KiB).  Every lane of the
+// (single-wave) workgroup calls this with the same arguments.  Returns 0, -1 (malformed) or -2 (checksum); *used = the
+// bytes of the frame, *made = its content bytes.
+__device__ int lz_decode_frame(LzLds &L, const uint8_t *in, uint32_t n, uint8_t *dst, uint32_t cap, uint8_t *lit, uint32_t *used, uint32_t *made)
 {
     const uint32_t lane = threadIdx.x;
     uint32_t hdr;
     long long fcs;
     int ck;
+    *used = 0; *made = 0;
     if (LZU(frame_header(in, n, &hdr, &fcs, &ck) < 0)) return -1;
+    if (fcs >= 0 && (unsigned long long)fcs > cap) return -1;
+    const uint32_t raw = fcs >= 0 ? LZU((uint32_t)fcs) : cap;
     uint32_t pos = LZU(hdr), out = 0;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
     if (lane == 0) { L.have_huf = L.have_ll = L.have_of = L.have_ml = 0; }
@@ -305,12 +310,14 @@ __device__ int lz_decode_frame(LzLds &L, const uint8_t *in, uint32_t n, uint8_t 
         if (last) break;
     }
     if (ck) { // Content_Checksum: low 32 bits of XXH64 over the frame's content (four lanes hash; a 15 MB stock frame is a long serial chain)
-        if (n - pos < 4 || out != raw) return -1;
+        if (n - pos < 4 || (fcs >= 0 && out != raw)) return -1;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        const unsigned long long h = xxh64_quad(dst, lane < 4 ? raw : 0u, lane);
+        const unsigned long long h = xxh64_quad(dst, lane < 4 ? out : 0u, lane);
         const uint32_t want = in[pos] | ((uint32_t)in[pos + 1] << 8) | ((uint32_t)in[pos + 2] << 16) | ((uint32_t)in[pos + 3] << 24);
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)h) != want) return -2;
         pos += 4;
     }
-    return (pos == n && out == raw) ? 0 : -1;
+    *used = pos;
+    *made = out;
+    return (fcs < 0 || out == raw) ? 0 : -1;
 }

@@ -15,6 +15,7 @@
 #include "fqz_device.h"
 #include "fqz_entropy_dev.h"
 #include "fqz_xxh.h"
+#include "fqz_hdrlz.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -834,7 +835,8 @@ __device__ __forceinline__ uint32_t h2_frame_hdr(uint32_t M) { return M < 256u ?
 // group: its content is hashed by k_xxh) and, unless the stream is the 2-bit packed bases, to gmap (k_entropy).  The bases
 // are Raw blocks by definition: their "compressed" size is known here and k_compact copies them straight from the arena.
 // cinfo[chunk] = block | stream << 24, for k_compact (which would otherwise repeat the search, one dependent load after another)
-__global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPlan *plans, uint4 *gmap, uint4 *xmap, uint32_t group_cap, uint32_t *cinfo, uint32_t *csize)
+__global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPlan *plans, uint4 *gmap, uint4 *hmap, uint4 *xmap, uint32_t group_cap, uint32_t *cinfo, uint32_t *csize,
+                                                   uint32_t *hord, uint32_t *hlist, uint32_t hcap)
 {
     const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
     if (chunk >= info->n_chunks) return;
@@ -845,12 +847,22 @@ __global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPla
     const BlockPlan *p = &plans[b];
     const uint32_t off = c * FQZ_CHUNK;
     if (s == S_SEQ) csize[chunk] = 3u + (p->len[s] - off < FQZ_CHUNK ? p->len[s] - off : FQZ_CHUNK); // Raw block: header + bytes
+    if (s == S_HDR) { // headers chunks are modelled first (fqz_hdrlz.h): ordinal = slot in the side buffers
+        const uint32_t o = atomicAdd(&info->n_hchunks, 1u);
+        hord[chunk] = o;
+        if (o < hcap) hlist[o] = chunk;
+    }
     if (c % FQZ_GROUP) return;
     const uint32_t M = p->len[s] - off < FQZ_GROUP * FQZ_CHUNK ? p->len[s] - off : FQZ_GROUP * FQZ_CHUNK;
     const uint4 d = make_uint4(chunk, p->a_off[s] + off, M | ((uint32_t)s << 28), 0u);
     const uint32_t x = atomicAdd(&info->n_xgroups, 1u); // any order: groups are independent
     if (x < group_cap) xmap[x] = d;
     if (s == S_SEQ) return;
+    if (s == S_HDR) {
+        const uint32_t g = atomicAdd(&info->n_hgroups, 1u);
+        if (g < group_cap) hmap[g] = d;
+        return;
+    }
     const uint32_t g = atomicAdd(&info->n_groups, 1u);
     if (g < group_cap) gmap[g] = d;
 }
@@ -864,7 +876,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const uint32_t chunk = gd.x, M = gd.z & 0xFFFFFFu, s = gd.z >> 28;
     if (stamps) { stamps += (size_t)chunk * 16; if (threadIdx.x == 0) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[15] = (unsigned long long)s; } }
     const uint8_t *src = (s == S_NPOS ? npos_arena : arena) + gd.y; // 16-byte aligned
-    entropy_encode_group(S, src, M, 0u, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
+    entropy_encode_group<false>(S, src, M, 0u, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
+}
+
+// ---- headers stream: model (sequences + literals per chunk), Sequences_Sections, then the entropy stage over the literals
+__global__ __launch_bounds__(256) void k_hdr_model(const EncInfo *info, const BlockPlan *plans, const uint32_t *cinfo, const uint32_t *hlist, uint32_t hcap, const uint32_t *Eh,
+                                                   const uint8_t *arena, uint2 *hseq, uint8_t *hlit, HdrSide *side)
+{
+    __shared__ __attribute__((aligned(16))) HdrModelLds S;
+    const uint32_t o = blockIdx.x;
+    if (o >= info->n_hchunks || o >= hcap) return;
+    const uint32_t chunk = hlist[o];
+    const BlockPlan *p = &plans[cinfo[chunk] & 0xFFFFFFu];
+    const uint32_t c0 = (chunk - p->chunk_base[S_HDR]) * FQZ_CHUNK, len = p->len[S_HDR];
+    const uint32_t mk = len - c0 < FQZ_CHUNK ? len - c0 : FQZ_CHUNK;
+    hdr_model_chunk(S, arena + p->a_off[S_HDR], Eh, p->rec0, p->nrec, c0, mk, hseq + (size_t)o * HDR_MAX_SEQ, hlit + (size_t)o * FQZ_CHUNK, &side[o]);
+}
+
+__global__ __launch_bounds__(64) void k_hdr_seq(const EncInfo *info, uint32_t hcap, const uint2 *hseq, uint8_t *hsec, HdrSide *side)
+{
+    const uint32_t o = blockIdx.x * 64 + threadIdx.x;
+    if (o >= info->n_hchunks || o >= hcap) return;
+    const uint32_t nseq = side[o].nseq;
+    if (nseq) hdr_encode_sequences(hseq + (size_t)o * HDR_MAX_SEQ, nseq, hsec + (size_t)o * HDR_SEQ_CAP, &side[o]);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_entropy_hdr(const EncInfo *info, const uint4 *hmap, const uint8_t *arena, uint8_t *slots, uint32_t *csize,
+                                                     const uint32_t *hord, uint32_t hcap, const uint8_t *hlit, const uint8_t *hsec, const HdrSide *side)
+{
+    __shared__ __attribute__((aligned(16))) EntropyLds S;
+    __shared__ HdrGroup H;
+    if (blockIdx.x >= info->n_hgroups) return;
+    const uint4 gd = hmap[blockIdx.x];
+    const uint32_t chunk = gd.x, M = gd.z & 0xFFFFFFu, t = threadIdx.x;
+    const uint8_t *src = arena + gd.y;
+    if (t < (M + FQZ_CHUNK - 1) / FQZ_CHUNK) {
+        const uint32_t mk = M - t * FQZ_CHUNK < FQZ_CHUNK ? M - t * FQZ_CHUNK : FQZ_CHUNK, o = hord[chunk + t];
+        HdrSide sd = {0, mk, 0, 0};
+        if (o < hcap) sd = side[o];
+        H.nseq[t] = sd.nseq; H.n_lit[t] = sd.nseq ? sd.n_lit : mk; H.ssz[t] = sd.sec_len;
+        H.lit[t] = sd.nseq ? hlit + (size_t)o * FQZ_CHUNK : src + (size_t)t * FQZ_CHUNK;
+        H.sec[t] = hsec + (size_t)(o < hcap ? o : 0) * HDR_SEQ_CAP;
+    }
+    __syncthreads();
+    entropy_encode_group<true>(S, src, M, 0u, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], 0, nullptr, &H);
 }
 
 // Content checksum of every frame (= group): four lanes per group, 16 groups per wave (fqz_xxh.h).  xsum[first chunk] = low 32 bits.
@@ -959,7 +1014,7 @@ __device__ __forceinline__ void put_le32(uint8_t *p, uint32_t v) { p[0] = (uint8
 
 // csize has been scanned in place (exclusive prefix, total at [n_chunks])
 // one 256-thread workgroup, one thread per block: block size = 36 + its six frames, offsets by a workgroup scan
-__global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap)
+__global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap, uint32_t hcap)
 {
     __shared__ uint32_t sh[4];
     if (blockIdx.x) return;
@@ -968,6 +1023,7 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
         info->status = -(int32_t)(info->error_key & 31);
         info->error_record = (uint32_t)(info->error_key >> 8);
     }
+    if (t == 0 && info->n_hchunks > hcap && info->status == 0) info->status = FQZ_E_TOO_LARGE; // headers side buffers too small: the host relaunches
     __syncthreads();
     const uint32_t n_blocks = info->status ? 0u : info->n_blocks;
     unsigned long long carry = 0; // bytes of the blocks of earlier strips
@@ -1165,7 +1221,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         const size_t slot_bytes = (size_t)e.chunk_cap * FQZ_SLOT, local_bytes = 5ull * e.n_tiles * LL_CAP + 64; // (see k_line_local)
         if ((rc = e.slots.ensure(slot_bytes > local_bytes ? slot_bytes : local_bytes))) return rc;
     }
-    if ((rc = e.csize.ensure(4ull * (2ull * e.chunk_cap + 4)))) return rc; // compressed sizes (scanned in place) | cinfo
+    if ((rc = e.csize.ensure(4ull * (3ull * e.chunk_cap + 8)))) return rc; // compressed sizes (scanned in place) | cinfo | hord
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
     if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
 
@@ -1220,11 +1276,24 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
     PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, npos));
     const uint32_t group_cap = e.chunk_cap / FQZ_GROUP + FQZ_NS * e.block_cap + 8;
-    if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
+    if ((rc = e.gmap.ensure(32ull * group_cap))) return rc; // gmap | hmap
     if ((rc = e.xmap.ensure(16ull * group_cap + 4ull * (e.chunk_cap + 8)))) return rc;
     uint32_t *xsum = (uint32_t *)(e.xmap.as<uint4>() + group_cap);
-    PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), e.xmap.as<uint4>(), group_cap,
-                                                    csize + e.chunk_cap + 2, csize));
+    uint32_t *cinfo = csize + e.chunk_cap + 2, *hord = csize + 2ull * e.chunk_cap + 4;
+    uint4 *hmap = e.gmap.as<uint4>() + group_cap;
+    // side buffers of the headers model: per headers chunk its sequences, literals, Sequences_Section (fqz_hdrlz.h).  Sized for
+    // a quarter of the text being headers; a batch with more is relaunched with the exact need (fqz_enc_finish)
+    uint32_t hcap = (uint32_t)(n / (4ull * FQZ_CHUNK)) + 2 * e.block_cap + 64;
+    if (e.hcap_need > hcap && e.n_bytes == n_bytes) hcap = e.hcap_need;
+    if ((size_t)hcap > main_cap) hcap = (uint32_t)main_cap;
+    e.hcap = hcap;
+    if ((rc = e.hside.ensure((size_t)hcap * (8ull * HDR_MAX_SEQ + FQZ_CHUNK + HDR_SEQ_CAP + sizeof(HdrSide) + 4) + 256))) return rc;
+    uint2 *hseq = e.hside.as<uint2>();
+    uint8_t *hlit = (uint8_t *)(hseq + (size_t)hcap * HDR_MAX_SEQ), *hsec = hlit + (size_t)hcap * FQZ_CHUNK;
+    HdrSide *hside = (HdrSide *)(hsec + (size_t)hcap * HDR_SEQ_CAP);
+    uint32_t *hlist = (uint32_t *)(hside + hcap);
+    PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), hmap, e.xmap.as<uint4>(), group_cap,
+                                                    cinfo, csize, hord, hlist, hcap));
     // the content checksums need the streams only: they are hashed on a side stream beside the entropy coder (a chain of
     // memory round trips with a few waves per CU beside a kernel bound by instruction issue) and joined before k_compact
     if (!e.side) {
@@ -1234,12 +1303,17 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     }
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side, e.ev_fork, 0));
+    // the headers chain (model -> sequences -> entropy over the literals) runs beside the entropy coder of the other streams too
+    const uint32_t hgroup_cap = hcap / FQZ_GROUP + e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + e.block_cap + 8 : group_cap;
+    PROF(ctx, e.side, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, e.side, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside));
+    PROF(ctx, e.side, "k_hdr_seq", hipLaunchKernelGGL(k_hdr_seq, dim3((hcap + 63) / 64), dim3(64), 0, e.side, info, hcap, hseq, hsec, hside));
+    PROF(ctx, e.side, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, e.side, info, hmap, arena, slots, csize, hord, hcap, hlit, hsec, hside));
     PROF(ctx, e.side, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, e.side, info, e.xmap.as<uint4>(), arena, npos, xsum));
     HIP_TRY(hipEventRecord(e.ev_join, e.side));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
-    if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
-    PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join, 0));
+    if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
+    PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap, hcap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, xsum, arena, d_out, (uint32_t)S_SEQ));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
@@ -1270,6 +1344,10 @@ int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uin
         // a tile with more lines than a tile-local slot holds: this batch is redone, and the next ones are done, with the
         // two-pass index (such inputs come in runs; after 16 launches the single-pass index gets another try)
         e.two_pass_left = 16;
+        return FQZ_E_TOO_LARGE;
+    }
+    if (hi->status == FQZ_E_TOO_LARGE && hi->n_hchunks > e.hcap) { // more headers chunks than side buffers: relaunch with the exact need
+        e.hcap_need = hi->n_hchunks + 16;
         return FQZ_E_TOO_LARGE;
     }
     if (hi->status == FQZ_E_TOO_LARGE && hi->n_lines > e.line_cap) {
@@ -1350,11 +1428,12 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;
     if ((rc = e.xmap.ensure(16ull * group_cap + 4ull * (chunks + 8)))) return rc;
     uint32_t *xsum = (uint32_t *)(e.xmap.as<uint4>() + group_cap);
-    hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), e.xmap.as<uint4>(), group_cap, csize + chunks + 2, csize);
+    hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), (uint4 *)nullptr, e.xmap.as<uint4>(), group_cap, csize + chunks + 2, csize,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
     PROF(ctx, st, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, st, info, e.xmap.as<uint4>(), d_src, d_src, xsum));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_dst, cap);
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_dst, cap, 0u);
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks ? chunks : 1), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, csize + chunks + 2, xsum, d_src, d_dst, (uint32_t)S_SEQ));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));

@@ -346,13 +346,26 @@ __device__ __forceinline__ void load_chunk_syms(EntropyLds &S, const uint8_t *sr
 
 // Every group is a zstd frame of its own (FQZ-H2): its last chunk carries the Last_Block bit.  force_raw: the 2-bit packed
 // bases are Raw blocks by definition - no histogram, no table, no bit counting.
+//
+// HDR (headers stream, fqz_hdrlz.h): chunk k has been modelled into H->nseq[k] sequences (their Sequences_Section: H->sec[k],
+// H->ssz[k] bytes) and H->n_lit[k] literals at H->lit[k]; the table is built over the literals, the block carries the
+// Huffman-coded literals followed by the sequences.  A chunk without sequences has lit = the chunk itself.
+struct HdrGroup {
+    const uint8_t *lit[FQZ_GROUP];
+    const uint8_t *sec[FQZ_GROUP];
+    uint32_t n_lit[FQZ_GROUP], nseq[FQZ_GROUP], ssz[FQZ_GROUP];
+};
+#define HDR_SEC_OVERFLOW 0xFFFFFFFFu
+
+template <bool HDR>
 __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const uint32_t M, const uint32_t force_raw, uint8_t *slot0, uint32_t *csize0,
-                                     const int dbg_stop = 0, unsigned long long *stamps = nullptr)
+                                     const int dbg_stop = 0, unsigned long long *stamps = nullptr, const HdrGroup *H = nullptr)
 {
     const uint32_t last = 1;
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const uint32_t nchunk = (M + FQZ_CHUNK - 1) / FQZ_CHUNK;
-    const uint32_t m = M; // the table-build code below speaks of "m": the byte count the histogram covers
+    uint32_t m = M; // the table-build code below speaks of "m": the byte count the histogram covers
+    if (HDR) { m = 0; for (uint32_t k = 0; k < nchunk; k++) m += H->n_lit[k]; }
     // ---- phase 1: histogram of the whole group; per chunk, whether all its bytes are equal (RLE block).
     //      Skewed data (quality deltas are ~90 % zeros) would serialise LDS atomics on one bin, so every wave first peels
     //      off its dominant byte: the candidate is the first byte the wave sees, matches are counted with SWAR compares
@@ -362,9 +375,9 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
 #pragma clang loop unroll(disable)
     for (uint32_t k = 0; k < (force_raw ? 0u : nchunk); k++) {
         const uint32_t mk = M - k * FQZ_CHUNK < FQZ_CHUNK ? M - k * FQZ_CHUNK : FQZ_CHUNK;
-        const uint8_t *csrc = src + (size_t)k * FQZ_CHUNK;
+        const uint8_t *csrc = HDR ? H->lit[k] : src + (size_t)k * FQZ_CHUNK;
         ChunkSyms C;
-        load_chunk_syms(S, csrc, mk, C);
+        load_chunk_syms(S, csrc, HDR ? H->n_lit[k] : mk, C);
         const uint32_t b0 = (uint32_t)csrc[0] * 0x01010101u;
         const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(C.sym[0] & 0xFF)); // wave-uniform candidate byte
         const uint32_t cand4 = cand * 0x01010101u;
@@ -384,7 +397,7 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
         }
         n_cand = wave_sum(n_cand);
         if (lane == 0 && n_cand) atomicAdd(&S.ctab[cand], n_cand);
-        if (!__syncthreads_or(differs != 0)) same_mask |= 1u << k;
+        if (!__syncthreads_or(differs != 0) && !(HDR && H->nseq[k])) same_mask |= 1u << k;
     }
     DBG_STOP(1);
     uint32_t *const keys = lds_keys(S), *const sorted = lds_sorted(S);
@@ -623,9 +636,13 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
             continue;
         }
         uint32_t cmode = mode; // 2 = Huffman with the group table, anything else = raw
+        const uint32_t nseq = HDR ? H->nseq[k] : 0u;
+        const uint32_t ml = HDR ? H->n_lit[k] : mk;       // literals of the block (== the chunk when there are no sequences)
+        const uint32_t sec_sz = nseq ? H->ssz[k] : 1u;       // Sequences_Section bytes (Number_of_Sequences = 0: one byte)
+        if (HDR && sec_sz == HDR_SEC_OVERFLOW) cmode = 0;
         if (cmode == 2) {
             ChunkSyms C;
-            load_chunk_syms(S, csrc, mk, C);
+            load_chunk_syms(S, HDR ? H->lit[k] : csrc, ml, C);
             for (uint32_t i = t; i < OUT_WORDS; i += 256) S.out[i] = 0;
             // ---- pass 1: bits per lane, per stream (wave w encodes stream w)
             uint32_t my_bits = 0;
@@ -650,8 +667,8 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
                 uint32_t ssz[4] = {0, 0, 0, 0}, total_streams = 0;
                 for (uint32_t q = 0; q < nstreams; q++) { ssz[q] = (S.misc[8 + q] >> 3) + 1; total_streams += ssz[q]; }
                 const uint32_t lit_csize = tsz + (nstreams == 4 ? 6 : 0) + total_streams;
-                const uint32_t lh = mk < 1024 ? 3 : (mk < 16384 ? 4 : 5);
-                const uint32_t content = lh + lit_csize + 1;
+                const uint32_t lh = ml < 1024 ? 3 : (ml < 16384 ? 4 : 5);
+                const uint32_t content = lh + lit_csize + sec_sz;
                 if (content >= mk) S.misc[5] = 0;
                 else {
                     S.misc[5] = 2;
@@ -660,13 +677,13 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
                     const uint32_t lt = tree_sent ? 3u : 2u; // treeless once the group's table has been sent
                     o[0] = (uint8_t)bh; o[1] = (uint8_t)(bh >> 8); o[2] = (uint8_t)(bh >> 16);
                     if (lh == 3) {
-                        uint32_t v = lt | ((nstreams == 4 ? 1u : 0u) << 2) | (mk << 4) | (lit_csize << 14);
+                        uint32_t v = lt | ((nstreams == 4 ? 1u : 0u) << 2) | (ml << 4) | (lit_csize << 14);
                         o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16);
                     } else if (lh == 4) {
-                        uint32_t v = lt | (2u << 2) | (mk << 4) | (lit_csize << 18);
+                        uint32_t v = lt | (2u << 2) | (ml << 4) | (lit_csize << 18);
                         o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
                     } else {
-                        uint32_t v = lt | (3u << 2) | (mk << 4) | (lit_csize << 22);
+                        uint32_t v = lt | (3u << 2) | (ml << 4) | (lit_csize << 22);
                         o[3] = (uint8_t)v; o[4] = (uint8_t)(v >> 8); o[5] = (uint8_t)(v >> 16); o[6] = (uint8_t)(v >> 24);
                         o[7] = (uint8_t)(lit_csize >> 10);
                     }
@@ -676,8 +693,9 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
                         pos += 6;
                     }
                     for (uint32_t q = 0; q < 4; q++) { S.misc[8 + q] = pos; pos += ssz[q]; } // stream start bytes
-                    o[pos] = 0;                                                                // Number_of_Sequences = 0
-                    S.misc[12] = pos + 1;
+                    if (!nseq) o[pos] = 0;                                                     // Number_of_Sequences = 0
+                    S.misc[12] = pos + sec_sz;
+                    S.misc[15] = pos;
                     S.misc[14] = 3 + lh; // tree offset
                 }
             }
@@ -720,6 +738,12 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
                     if (fill > 32) atomicOr(&S.out[word + 1], (uint32_t)(acc >> 32));
                 }
                 __syncthreads();
+                if (HDR && nseq) { // the Sequences_Section behind the literals
+                    uint8_t *o8 = (uint8_t *)S.out + S.misc[15];
+                    const uint8_t *sec = H->sec[k];
+                    for (uint32_t i = t; i < sec_sz; i += 256) o8[i] = sec[i];
+                    __syncthreads();
+                }
                 const uint32_t total = S.misc[12];
                 uint32_t *slot32 = (uint32_t *)slot;
                 for (uint32_t i = t; i < (total + 3) / 4; i += 256) slot32[i] = S.out[i];
@@ -729,6 +753,22 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
                 continue;
             }
             __syncthreads();
+        }
+        if (HDR && mode != 2 && nseq && sec_sz != HDR_SEC_OVERFLOW) { // no table for this group: the literals of a block with sequences travel raw
+            const uint32_t lh = ml < 32 ? 1u : (ml < 4096 ? 2u : 3u), content = lh + ml + sec_sz;
+            if (content < mk) {
+                if (t == 0) {
+                    const uint32_t bh = lastblk | (2u << 1) | (content << 3);
+                    slot[0] = (uint8_t)bh; slot[1] = (uint8_t)(bh >> 8); slot[2] = (uint8_t)(bh >> 16);
+                    const uint32_t v = lh == 1 ? ml << 3 : (((lh == 2 ? 1u : 3u) << 2) | (ml << 4)); // Raw_Literals_Block, size format by lh
+                    for (uint32_t q = 0; q < lh; q++) slot[3 + q] = (uint8_t)(v >> (8 * q));
+                    csize0[k] = 3 + content;
+                }
+                const uint8_t *lit = H->lit[k], *sec = H->sec[k];
+                for (uint32_t i = t; i < ml; i += 256) slot[3 + lh + i] = lit[i];
+                for (uint32_t i = t; i < sec_sz; i += 256) slot[3 + lh + ml + i] = sec[i];
+                continue;
+            }
         }
         // raw block: 3-byte header + the mk bytes, copied from global memory (L2-hot) with 128-bit accesses
         {

@@ -33,6 +33,8 @@ struct EncInfo {
     uint32_t npos_used;
     uint32_t index_overflow; // a 4 KiB tile holds more lines than its tile-local slot (k_line_local)
     uint32_t n_xgroups;     // all chunk groups = zstd frames, the Raw ones of the packed bases included (k_xxh)
+    uint32_t n_hchunks;     // chunks of the headers streams (modelled before the entropy stage, fqz_hdrlz.h)
+    uint32_t n_hgroups;     // their groups
     unsigned long long error_key; // (record << 8 | check order << 4 | code index), min wins
     unsigned long long out_len;
     unsigned long long stream_raw[FQZ_NS];

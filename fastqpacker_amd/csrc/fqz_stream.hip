@@ -32,7 +32,7 @@ size_t slice_bytes()
 {
     const char *e = getenv("FQZ_SLICE_KB"); // (tests use small slices to drive many batches through small inputs)
     const size_t kb = e ? (size_t)strtoull(e, nullptr, 10) : 0;
-    return kb ? kb << 10 : (size_t)256 << 20;
+    return kb ? kb << 10 : (size_t)128 << 20;
 }
 
 struct Io { // the two ends of a stream job: either plain memory (copied to / from the device directly) or callbacks
@@ -221,7 +221,7 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts)
         for (int attempt = 0;; attempt++) {
             rc = fqz_enc_launch(lane, d_text, n_text, rpb, enc, final_batch ? FQZ_BATCH_FINAL : 0, lane->d_out.as<uint8_t>(), cap, lane->stream);
             if (!rc) rc = fqz_enc_finish(lane, &res, nullptr, nullptr, 0);
-            if (rc == FQZ_E_TOO_LARGE && attempt < 2) continue; // the context has resized itself (very short lines): same launch again
+            if (rc == FQZ_E_TOO_LARGE && attempt < 3) continue; // the context has resized itself (very short lines): same launch again
             break;
         }
         if (rc) { P.fail(rc); break; }                                  // "parsing FASTQ: ..." / "compressing block: ..."

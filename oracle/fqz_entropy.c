@@ -303,20 +303,216 @@ static size_t huf_stream(const uint8_t *src, size_t n, const uint16_t *code, con
  * description, the others are "treeless" (Literals_Block_Type 3, RFC 8878 3.1.1.3.1.1: reuse the previous table).
  * On the GPU the table build (sort, Huffman merge, FSE weight coding) is a quarter of the LDS traffic of a chunk; a
  * group pays it once for four blocks, and the decoder builds four times fewer tables. */
-static size_t encode_group_ex(const uint8_t *src, size_t M, int last, int force_raw, uint8_t *dst);
-size_t fqzo_encode_group(const uint8_t *src, size_t M, int last, uint8_t *dst) { return encode_group_ex(src, M, last, 0, dst); }
-static size_t encode_group_ex(const uint8_t *src, size_t M, int last, int force_raw, uint8_t *dst)
+/* ===================================================================== */
+/* header-stream modelling: matches with the previous record as zstd       */
+/* sequences (RFC 8878 3.1.1.3.2) with the predefined FSE tables            */
+/* ===================================================================== */
+/* The headers stream is [u16 H][H bytes] per record (compress.go:514-515) and consecutive Illumina headers share a long
+ * prefix and a long suffix.  Inside one 16 KiB chunk (= one zstd block; matches never leave the block, so blocks stay
+ * independent) every record that lies wholly inside the chunk, and whose predecessor does too, is compared with its
+ * predecessor: a = common prefix, b = common suffix of what is left.  The suffix of record i (aligned at the ends: offset
+ * = length of record i) and the prefix of record i + 1 (aligned at the starts: offset = length of record i again) are
+ * adjacent and share their offset, so every record boundary gives at most ONE match, of b_i + a_{i+1} bytes at offset
+ * len_i; it is emitted when it is at least HDR_MIN_MATCH bytes long.  Everything else is literals (Huffman-coded with
+ * the group's table as before).  Offsets are always coded explicitly (Offset_Value = offset + 3), never as repeat
+ * offsets, so that no block depends on the offset history its predecessors leave behind; all three symbol types use
+ * Predefined_Mode, so there is no table description to build. */
+#define HDR_MIN_MATCH 6
+#define HDR_MAX_SEQ 2048 /* per chunk; a chunk with more records inside is coded without matches */
+typedef struct { uint32_t ll, ml, off; } hseq;
+
+static const short LL_NORM[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+static const short ML_NORM[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+static const short OF_NORM[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+static const uint32_t LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40,
+                                     48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+static const uint8_t LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+static const uint32_t ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+                                     30, 31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195,
+                                     16387, 32771, 65539};
+static const uint8_t ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                    0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+
+/* FSE compression table of a normalised distribution (counts may be -1 = "less than one"): FSE_buildCTable */
+typedef struct { uint16_t state[512]; int32_t dnb[64], dfs[64]; int log; } fse_ct;
+static void fse_build_ct(fse_ct *ct, const short *norm, int nsym, int log)
+{
+    const int size = 1 << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    int cumul[65];
+    uint8_t tsym[512];
+    int high = size - 1;
+    cumul[0] = 0;
+    for (int u = 1; u <= nsym; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tsym[high--] = (uint8_t)(u - 1); }
+        else cumul[u] = cumul[u - 1] + norm[u - 1];
+    }
+    int pos = 0;
+    for (int sy = 0; sy < nsym; sy++)
+        for (int k = 0; k < norm[sy]; k++) {
+            tsym[pos] = (uint8_t)sy;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    for (int u = 0; u < size; u++) { const int sy = tsym[u]; ct->state[cumul[sy]++] = (uint16_t)(size + u); }
+    int total = 0;
+    for (int sy = 0; sy < nsym; sy++) {
+        const int n = norm[sy];
+        if (n == 0) { ct->dnb[sy] = ((log + 1) << 16) - (1 << log); ct->dfs[sy] = 0; }
+        else if (n == -1 || n == 1) { ct->dnb[sy] = (log << 16) - (1 << log); ct->dfs[sy] = total - 1; total++; }
+        else {
+            const int maxbits = log - highbit32((uint32_t)(n - 1));
+            ct->dnb[sy] = (maxbits << 16) - (n << maxbits);
+            ct->dfs[sy] = total - n;
+            total += n;
+        }
+    }
+    ct->log = log;
+}
+static inline uint32_t fse_init_state(const fse_ct *ct, int sy) /* FSE_initCState2 */
+{
+    const uint32_t nb = (uint32_t)(ct->dnb[sy] + (1 << 15)) >> 16;
+    const uint32_t value = (nb << 16) - (uint32_t)ct->dnb[sy];
+    return ct->state[(value >> nb) + (uint32_t)ct->dfs[sy]];
+}
+static inline uint32_t fse_encode(const fse_ct *ct, bitw *bw, uint32_t st, int sy) /* FSE_encodeSymbol */
+{
+    const uint32_t nb = (st + (uint32_t)ct->dnb[sy]) >> 16;
+    bw_add(bw, st & ((1u << nb) - 1), (int)nb);
+    return ct->state[(st >> nb) + (uint32_t)ct->dfs[sy]];
+}
+static inline int ll_code(uint32_t ll)
+{
+    static const uint8_t T[64] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 20, 20, 21, 21, 21, 21,
+                                  22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23, 23, 23, 23, 23, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
+    return ll < 64 ? T[ll] : highbit32(ll) + 19;
+}
+static inline int ml_code(uint32_t mlb) /* mlb = match length - 3 */
+{
+    static const uint8_t T[128] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31,
+                                   32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 36, 37, 37, 37, 37, 38, 38, 38, 38, 38, 38, 38, 38, 39, 39, 39, 39, 39, 39, 39, 39,
+                                   40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41,
+                                   42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42};
+    return mlb < 128 ? T[mlb] : highbit32(mlb) + 36;
+}
+
+/* Sequences_Section of n > 0 sequences: count, modes byte (all Predefined), bitstream (ZSTD_encodeSequences order) */
+static size_t hdr_write_sequences(const hseq *sq, uint32_t n, uint8_t *dst)
+{
+    static fse_ct LL, ML, OF;
+    static int ready = 0;
+    if (!ready) { fse_build_ct(&LL, LL_NORM, 36, 6); fse_build_ct(&ML, ML_NORM, 53, 6); fse_build_ct(&OF, OF_NORM, 29, 5); ready = 1; }
+    uint8_t *op = dst;
+    if (n < 128) *op++ = (uint8_t)n;
+    else { *op++ = (uint8_t)((n >> 8) + 128); *op++ = (uint8_t)n; } /* n < 0x7F00 */
+    *op++ = 0; /* Symbol_Compression_Modes: Predefined_Mode x 3 */
+    bitw bw = { op, 0, 0 };
+    /* Offset_Value: 1 = "the offset of the previous sequence" (legal when this sequence has literals, RFC 8878 3.1.1.5) for a
+     * sequence whose offset repeats the previous one of THIS block; offset + 3 otherwise.  The first sequence of a block is
+     * always explicit, so no block depends on the offset history its predecessors leave behind. */
+#define HDR_OFV(k) (((k) > 0 && sq[k].off == sq[(k) - 1].off && sq[k].ll > 0) ? 1u : sq[k].off + 3u)
+    uint32_t i = n - 1;
+    uint32_t ofv = HDR_OFV(i);
+    int lc = ll_code(sq[i].ll), mc = ml_code(sq[i].ml - 3), oc = highbit32(ofv);
+    uint32_t st_ml = fse_init_state(&ML, mc), st_of = fse_init_state(&OF, oc), st_ll = fse_init_state(&LL, lc);
+    bw_add(&bw, sq[i].ll - LL_BASE[lc], LL_BITS[lc]);
+    bw_add(&bw, sq[i].ml - ML_BASE[mc], ML_BITS[mc]);
+    bw_add(&bw, ofv - (1u << oc), oc);
+    while (i-- > 0) {
+        ofv = HDR_OFV(i);
+        lc = ll_code(sq[i].ll); mc = ml_code(sq[i].ml - 3); oc = highbit32(ofv);
+        st_of = fse_encode(&OF, &bw, st_of, oc);
+        st_ml = fse_encode(&ML, &bw, st_ml, mc);
+        st_ll = fse_encode(&LL, &bw, st_ll, lc);
+        bw_add(&bw, sq[i].ll - LL_BASE[lc], LL_BITS[lc]);
+        bw_add(&bw, sq[i].ml - ML_BASE[mc], ML_BITS[mc]);
+        bw_add(&bw, ofv - (1u << oc), oc);
+    }
+#undef HDR_OFV
+    bw_add(&bw, st_ml & 63, 6); /* FSE_flushCState: ML, OF, LL */
+    bw_add(&bw, st_of & 31, 5);
+    bw_add(&bw, st_ll & 63, 6);
+    return (size_t)(bw_close(&bw) - dst);
+}
+
+/* sequences of chunk [c0, c0 + mk) of a headers stream whose records start at rs[0 .. nr) (rs[nr] = end of the stream);
+ * lit receives the literals (<= mk bytes).  Returns the number of sequences (0: no matches, lit = the chunk).
+ * Per record i that lies inside the chunk together with its predecessor p:
+ *   head_i : the common prefix with p (aligned at the starts: offset len_p); when the u16 length prefixes differ (headers
+ *            of different length) the comparison starts behind them, at byte 2
+ *   tail_i : the common suffix with p of what the head left (aligned at the ends: offset len_i)
+ * tail_i and head_{i+1} share their offset (len_i) and are merged when they touch.  Candidates shorter than HDR_MIN_MATCH
+ * stay literals. */
+static uint32_t hdr_chunk_model(const uint8_t *stream, const uint32_t *rs, uint32_t nr, uint32_t c0, uint32_t mk, hseq *sq, uint8_t *lit, uint32_t *n_lit)
+{
+    const uint32_t c1 = c0 + mk;
+    uint32_t lo = 0, hi = nr; /* first record that starts at or behind c0 */
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rs[mid] < c0) lo = mid + 1; else hi = mid; }
+    const uint32_t first = lo;
+    uint32_t n_in = 0;
+    while (first + n_in < nr && rs[first + n_in + 1] <= c1) n_in++;
+    if (2 * n_in > HDR_MAX_SEQ) n_in = 0;
+    uint32_t nseq = 0, prev_end = c0, nl = 0;
+    /* pending candidate (a tail waiting for the next record's head) */
+    uint32_t pend_pos = 0, pend_len = 0, pend_off = 0;
+#define HDR_EMIT(pos_, len_, off_) do { if ((len_) >= HDR_MIN_MATCH) { \
+        sq[nseq].ll = (pos_) - prev_end; sq[nseq].ml = (len_); sq[nseq].off = (off_); \
+        memcpy(lit + nl, stream + prev_end, (pos_) - prev_end); nl += (pos_) - prev_end; prev_end = (pos_) + (len_); nseq++; } } while (0)
+    for (uint32_t k = 1; k < n_in; k++) { /* k = 0 has no predecessor inside the chunk */
+        const uint32_t i = first + k, s = rs[i], e = rs[i + 1], len = e - s, ps = rs[i - 1], plen = s - ps;
+        const uint32_t lim = len < plen ? len : plen;
+        uint32_t h_start = s, h_len = 0;
+        while (h_len < lim && stream[s + h_len] == stream[ps + h_len]) h_len++;
+        if (h_len < HDR_MIN_MATCH) { /* behind the length prefixes */
+            h_start = s + 2; h_len = 0;
+            while (2 + h_len < lim && stream[s + 2 + h_len] == stream[ps + 2 + h_len]) h_len++;
+            if (h_len < HDR_MIN_MATCH) { h_start = s; h_len = 0; }
+        }
+        /* the head joins the pending tail of the predecessor when they touch (same offset: len_p) */
+        if (pend_len && h_len && h_start == s && pend_pos + pend_len == s) { pend_len += h_len; HDR_EMIT(pend_pos, pend_len, pend_off); }
+        else {
+            if (pend_len) HDR_EMIT(pend_pos, pend_len, pend_off);
+            if (h_len) HDR_EMIT(h_start, h_len, plen);
+        }
+        pend_len = 0;
+        /* tail: common suffix of what is left */
+        const uint32_t used = h_len ? (h_start + h_len) - s : 0;
+        uint32_t tl = 0, tlim = len - used < plen ? len - used : plen;
+        while (tl < tlim && stream[e - 1 - tl] == stream[s - 1 - tl]) tl++;
+        if (tl) { pend_pos = e - tl; pend_len = tl; pend_off = len; }
+    }
+    if (pend_len) HDR_EMIT(pend_pos, pend_len, pend_off);
+#undef HDR_EMIT
+    memcpy(lit + nl, stream + prev_end, c1 - prev_end);
+    nl += c1 - prev_end;
+    *n_lit = nl;
+    return nseq;
+}
+
+/* ===================================================================== */
+/* one group (= one zstd frame): a Huffman table over its literals, one    */
+/* zstd block per chunk                                                    */
+/* ===================================================================== */
+typedef struct {
+    const uint8_t *raw; uint32_t mk;       /* the chunk as it lies in the stream */
+    const uint8_t *lit; uint32_t n_lit;    /* its literals (== raw, mk when there are no sequences) */
+    const hseq *sq; uint32_t nseq;
+} gchunk;
+
+static size_t encode_group_chunks(const gchunk *ch, int nch, int force_raw, uint8_t *dst)
 {
     uint32_t count[256] = {0};
-    for (size_t i = 0; i < M; i++) count[src[i]]++;
-    int huff = 1;
+    size_t M = 0;
+    for (int k = 0; k < nch; k++) { for (uint32_t i = 0; i < ch[k].n_lit; i++) count[ch[k].lit[i]]++; M += ch[k].n_lit; }
+    int huff = 1, n_active = 0;
+    for (int sy = 0; sy < 256; sy++) n_active += count[sy] != 0;
     if (force_raw) huff = 0;                   /* 2-bit packed bases: Raw blocks by definition (FQZ-H2), no histogram at all */
-    else if (count[src[0]] == M) huff = 0;     /* one symbol: every chunk is an RLE block */
+    else if (n_active <= 1) huff = 0;          /* one symbol: every chunk is an RLE block (or, with sequences, has raw literals) */
     else if (M < 64) huff = 0;
     else {   /* near-flat histogram: collision entropy -log2(sum p^2) >= log2(230) = 7.85 bits bounds the Shannon entropy
               * from below, so a Huffman table could save < 2 %: store raw (this is what 2-bit packed bases look like) */
         uint64_t sq = 0;
-        for (int s = 0; s < 256; s++) sq += (uint64_t)count[s] * count[s];
+        for (int sy = 0; sy < 256; sy++) sq += (uint64_t)count[sy] * count[sy];
         if (sq * 230 <= (uint64_t)M * M) huff = 0;
     }
     uint8_t nbits[256];
@@ -331,66 +527,102 @@ static size_t encode_group_ex(const uint8_t *src, size_t M, int last, int force_
     }
     int tree_sent = 0;
     uint8_t *out = dst;
-    for (size_t off = 0; off < M; off += FQZO_CHUNK) {
-        const size_t m = M - off < FQZO_CHUNK ? M - off : FQZO_CHUNK;
-        const uint8_t *c = src + off;
-        const int lastblk = last && off + m == M;
-        int same = !force_raw;
+    uint8_t *seqsec = (uint8_t *)malloc(16 + 12 * (size_t)HDR_MAX_SEQ);
+    for (int k = 0; k < nch; k++) {
+        const size_t m = ch[k].n_lit, mk = ch[k].mk;
+        const uint8_t *c = ch[k].lit;
+        const int lastblk = k + 1 == nch;
+        const uint32_t nseq = ch[k].nseq;
+        int same = !force_raw && nseq == 0;
         for (size_t i = 1; same && i < m; i++) if (c[i] != c[0]) same = 0;
         if (same) { /* RLE block */
-            put_block_header(out, lastblk, 1, (uint32_t)m);
+            put_block_header(out, lastblk, 1, (uint32_t)mk);
             out[3] = c[0];
             out += 4;
             continue;
         }
-        if (!huff) { out += raw_block(c, m, lastblk, out); continue; }
-        int nstreams = m >= 256 ? 4 : 1;
-        size_t seg = nstreams == 4 ? (m + 3) / 4 : m;
-        size_t ssize[4] = {0, 0, 0, 0}, streams_total = 0;
-        for (int k = 0; k < nstreams; k++) {
-            size_t a = (size_t)k * seg, b = (k == nstreams - 1) ? m : a + seg;
-            uint64_t bits = 0;
-            for (size_t i = a; i < b; i++) bits += nbits[c[i]];
-            ssize[k] = (size_t)(bits >> 3) + 1;
-            streams_total += ssize[k];
-        }
+        const size_t ssz = nseq ? hdr_write_sequences(ch[k].sq, nseq, seqsec) : 1; /* Number_of_Sequences = 0: one byte */
+        size_t content = 0, lh = 0, lit_csize = 0, ssize[4] = {0, 0, 0, 0};
+        int nstreams = 1;
+        size_t seg = m;
         const size_t tsz = tree_sent ? 0 : tree_size;
-        size_t lit_csize = tsz + (nstreams == 4 ? 6 : 0) + streams_total;
-        size_t lh = m < 1024 ? 3 : (m < 16384 ? 4 : 5);
-        size_t content = lh + lit_csize + 1;
-        if (content >= m) { out += raw_block(c, m, lastblk, out); continue; }
-        const uint32_t lt = tree_sent ? 3u : 2u; /* treeless once the group's table has been sent */
+        if (huff) {
+            nstreams = m >= 256 ? 4 : 1;
+            seg = nstreams == 4 ? (m + 3) / 4 : m;
+            size_t streams_total = 0;
+            for (int q = 0; q < nstreams; q++) {
+                size_t a = (size_t)q * seg, b = (q == nstreams - 1) ? m : a + seg;
+                uint64_t bits = 0;
+                for (size_t i = a; i < b; i++) bits += nbits[c[i]];
+                ssize[q] = (size_t)(bits >> 3) + 1;
+                streams_total += ssize[q];
+            }
+            lit_csize = tsz + (nstreams == 4 ? 6 : 0) + streams_total;
+            lh = m < 1024 ? 3 : (m < 16384 ? 4 : 5);
+            content = lh + lit_csize + ssz;
+        } else if (nseq) { /* no table for this group: the literals of a block with sequences travel raw */
+            lh = m < 32 ? 1 : (m < 4096 ? 2 : 3);
+            content = lh + m + ssz;
+        }
+        if ((!huff && !nseq) || content >= mk) { out += raw_block(ch[k].raw, mk, lastblk, out); continue; }
         put_block_header(out, lastblk, 2, (uint32_t)content);
         uint8_t *op = out + 3;
-        if (lh == 3) {
-            uint32_t v = lt | ((nstreams == 4 ? 1u : 0u) << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 14);
-            op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16);
-        } else if (lh == 4) {
-            uint32_t v = lt | (2u << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 18);
-            op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); op[3] = (uint8_t)(v >> 24);
+        if (!huff) { /* Raw_Literals_Block */
+            if (lh == 1) op[0] = (uint8_t)(m << 3);
+            else if (lh == 2) { const uint32_t v = (1u << 2) | ((uint32_t)m << 4); op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); }
+            else { const uint32_t v = (3u << 2) | ((uint32_t)m << 4); op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); }
+            op += lh;
+            memcpy(op, c, m);
+            op += m;
         } else {
-            uint32_t v = lt | (3u << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 22);
-            op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); op[3] = (uint8_t)(v >> 24);
-            op[4] = (uint8_t)(lit_csize >> 10);
+            const uint32_t lt = tree_sent ? 3u : 2u; /* treeless once the group's table has been sent */
+            if (lh == 3) {
+                uint32_t v = lt | ((nstreams == 4 ? 1u : 0u) << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 14);
+                op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16);
+            } else if (lh == 4) {
+                uint32_t v = lt | (2u << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 18);
+                op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); op[3] = (uint8_t)(v >> 24);
+            } else {
+                uint32_t v = lt | (3u << 2) | ((uint32_t)m << 4) | ((uint32_t)lit_csize << 22);
+                op[0] = (uint8_t)v; op[1] = (uint8_t)(v >> 8); op[2] = (uint8_t)(v >> 16); op[3] = (uint8_t)(v >> 24);
+                op[4] = (uint8_t)(lit_csize >> 10);
+            }
+            op += lh;
+            memcpy(op, tree, tsz);
+            op += tsz;
+            tree_sent = 1;
+            if (nstreams == 4) {
+                for (int q = 0; q < 3; q++) { op[2 * q] = (uint8_t)ssize[q]; op[2 * q + 1] = (uint8_t)(ssize[q] >> 8); }
+                op += 6;
+            }
+            for (int q = 0; q < nstreams; q++) {
+                size_t a = (size_t)q * seg, b = (q == nstreams - 1) ? m : a + seg;
+                (void)huf_stream(c + a, b - a, code, nbits, op);
+                op += ssize[q];
+            }
         }
-        op += lh;
-        memcpy(op, tree, tsz);
-        op += tsz;
-        tree_sent = 1;
-        if (nstreams == 4) {
-            for (int k = 0; k < 3; k++) { op[2 * k] = (uint8_t)ssize[k]; op[2 * k + 1] = (uint8_t)(ssize[k] >> 8); }
-            op += 6;
-        }
-        for (int k = 0; k < nstreams; k++) {
-            size_t a = (size_t)k * seg, b = (k == nstreams - 1) ? m : a + seg;
-            (void)huf_stream(c + a, b - a, code, nbits, op);
-            op += ssize[k];
-        }
-        *op++ = 0; /* Number_of_Sequences = 0 */
+        if (nseq) { memcpy(op, seqsec, ssz); op += ssz; }
+        else *op++ = 0; /* Number_of_Sequences = 0 */
         out = op;
     }
+    free(seqsec);
     return (size_t)(out - dst);
 }
+
+/* a group of plain chunks: M consecutive bytes cut every FQZO_CHUNK */
+static size_t encode_group_ex(const uint8_t *src, size_t M, int last, int force_raw, uint8_t *dst)
+{
+    (void)last; /* every group is a frame of its own: its last chunk carries the Last_Block bit */
+    gchunk ch[FQZO_GROUP];
+    int nch = 0;
+    for (size_t off = 0; off < M; off += FQZO_CHUNK) {
+        const uint32_t m = (uint32_t)(M - off < FQZO_CHUNK ? M - off : FQZO_CHUNK);
+        ch[nch].raw = ch[nch].lit = src + off; ch[nch].mk = ch[nch].n_lit = m; ch[nch].sq = NULL; ch[nch].nseq = 0;
+        nch++;
+    }
+    return encode_group_chunks(ch, nch, force_raw, dst);
+}
+size_t fqzo_encode_group(const uint8_t *src, size_t M, int last, uint8_t *dst) { return encode_group_ex(src, M, last, 0, dst); }
 
 /* a single chunk = a group of one */
 size_t fqzo_encode_chunk(const uint8_t *src, size_t m, int last, uint8_t *dst) { return fqzo_encode_group(src, m, last, dst); }
@@ -466,12 +698,37 @@ size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint
     put32le(idx + 20, (uint32_t)chunks);
     uint8_t *ent = idx + FQZO_IDX_HDR;
     const size_t G = (size_t)FQZO_GROUP * FQZO_CHUNK;
+    /* headers stream: the record starts (a walk over the u16 length prefixes); anything that is not a clean chain of
+     * records is coded without matches */
+    uint32_t *rs = NULL, nr = 0;
+    if (stream == 2) {
+        rs = (uint32_t *)malloc(sizeof(uint32_t) * (n / 2 + 2));
+        size_t pos = 0;
+        while (pos + 2 <= n) { rs[nr++] = (uint32_t)pos; pos += 2 + (size_t)(src[pos] | (src[pos + 1] << 8)); }
+        if (pos != n) { free(rs); rs = NULL; nr = 0; } else rs[nr] = (uint32_t)n;
+    }
+    hseq *sqbuf = rs ? (hseq *)malloc(sizeof(hseq) * FQZO_GROUP * HDR_MAX_SEQ) : NULL;
+    uint8_t *litbuf = rs ? (uint8_t *)malloc(G) : NULL;
     for (size_t off = 0; off < n; off += G) {
         const size_t M = n - off < G ? n - off : G;
         op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
         if (M < 256) { op[4] = 0x24; op[5] = (uint8_t)M; op += 6; }                       /* single segment, checksum, FCS 1 byte */
         else { op[4] = 0x64; op[5] = (uint8_t)(M - 256); op[6] = (uint8_t)((M - 256) >> 8); op += 7; } /* FCS 2 bytes, value - 256 */
-        const size_t body = encode_group_ex(src + off, M, 1, stream == 0, op);
+        size_t body;
+        if (rs) {
+            gchunk ch[FQZO_GROUP];
+            int nch = 0;
+            for (size_t co = 0; co < M; co += FQZO_CHUNK, nch++) {
+                const uint32_t mk = (uint32_t)(M - co < FQZO_CHUNK ? M - co : FQZO_CHUNK);
+                uint32_t nl = 0;
+                ch[nch].raw = src + off + co; ch[nch].mk = mk;
+                ch[nch].sq = sqbuf + (size_t)nch * HDR_MAX_SEQ;
+                ch[nch].lit = litbuf + co;
+                ch[nch].nseq = hdr_chunk_model(src, rs, nr, (uint32_t)(off + co), mk, sqbuf + (size_t)nch * HDR_MAX_SEQ, litbuf + co, &nl);
+                ch[nch].n_lit = nl;
+            }
+            body = encode_group_chunks(ch, nch, 0, op);
+        } else body = encode_group_ex(src + off, M, 1, stream == 0, op);
         /* the index lists the size of every zstd block of the group */
         for (size_t q = 0; q < body;) {
             const uint32_t bh = op[q] | ((uint32_t)op[q + 1] << 8) | ((uint32_t)op[q + 2] << 16);
@@ -485,6 +742,7 @@ size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint
         put32le(op, (uint32_t)fqzo_xxh64(src + off, M, 0));
         op += 4;
     }
+    free(rs); free(sqbuf); free(litbuf);
     return (size_t)(op - dst);
 }
 
@@ -694,6 +952,82 @@ static int huf_decode_stream(const uint8_t *src, size_t n, const hdec *dt, int t
 /* the Huffman table of the previous Compressed literals of the frame, for treeless blocks */
 typedef struct { hdec dt[4096]; int table_log; int valid; } huf_state;
 
+/* Sequences_Section with Predefined_Mode tables (what the header modelling above writes; other modes are left to
+ * libzstd by the callers): dst[0 .. n_lit) holds the literals; the block is rebuilt in place from the end of a copy. */
+typedef struct { uint8_t sym, nb; uint16_t base; } fse_de;
+static void fse_build_dt(fse_de *dt, const short *norm, int nsym, int log)
+{
+    const int size = 1 << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint16_t next[64];
+    int high = size - 1;
+    for (int sy = 0; sy < nsym; sy++) {
+        if (norm[sy] == -1) { dt[high--].sym = (uint8_t)sy; next[sy] = 1; }
+        else next[sy] = (uint16_t)norm[sy];
+    }
+    int pos = 0;
+    for (int sy = 0; sy < nsym; sy++)
+        for (int k = 0; k < norm[sy]; k++) {
+            dt[pos].sym = (uint8_t)sy;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    for (int u = 0; u < size; u++) {
+        const uint32_t ns = next[dt[u].sym]++;
+        dt[u].nb = (uint8_t)(log - highbit32(ns));
+        dt[u].base = (uint16_t)((ns << dt[u].nb) - (uint32_t)size);
+    }
+}
+static long exec_sequences(const uint8_t *sec, size_t n, uint8_t *dst, size_t n_lit, size_t cap)
+{
+    static fse_de LLD[64], MLD[64], OFD[32];
+    static int ready = 0;
+    if (!ready) { fse_build_dt(LLD, LL_NORM, 36, 6); fse_build_dt(MLD, ML_NORM, 53, 6); fse_build_dt(OFD, OF_NORM, 29, 5); ready = 1; }
+    size_t p = 0;
+    uint32_t nseq = sec[p++];
+    if (nseq >= 128) { if (p >= n) return FQZO_E_ENTROPY; if (nseq == 255) return FQZO_E_ENTROPY; nseq = ((nseq - 128) << 8) + sec[p++]; }
+    if (p >= n || sec[p++] != 0) return FQZO_E_ENTROPY; /* Predefined_Mode for all three */
+    bitr br;
+    if (br_init(&br, sec + p, n - p) < 0) return FQZO_E_ENTROPY;
+    uint8_t *lit = (uint8_t *)malloc(n_lit ? n_lit : 1);
+    if (!lit) return FQZO_E_ENTROPY;
+    memcpy(lit, dst, n_lit);
+    uint32_t st_ll = br_read(&br, 6), st_of = br_read(&br, 5), st_ml = br_read(&br, 6);
+    uint32_t rep[3] = {1, 4, 8};
+    size_t out = 0, lpos = 0;
+    long err = 0;
+    for (uint32_t i = 0; i < nseq; i++) {
+        const int oc = OFD[st_of].sym, mc = MLD[st_ml].sym, lc = LLD[st_ll].sym;
+        const uint32_t of_val = (1u << oc) + br_read(&br, oc);
+        const uint32_t ml = ML_BASE[mc] + br_read(&br, ML_BITS[mc]);
+        const uint32_t ll = LL_BASE[lc] + br_read(&br, LL_BITS[lc]);
+        if (i + 1 < nseq) {
+            st_ll = LLD[st_ll].base + br_read(&br, LLD[st_ll].nb);
+            st_ml = MLD[st_ml].base + br_read(&br, MLD[st_ml].nb);
+            st_of = OFD[st_of].base + br_read(&br, OFD[st_of].nb);
+        }
+        uint32_t offset;
+        if (of_val > 3) { offset = of_val - 3; rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = offset; }
+        else {
+            const uint32_t idx = of_val + (ll == 0 ? 1u : 0u);
+            if (idx == 1) offset = rep[0];
+            else if (idx == 2) { offset = rep[1]; rep[1] = rep[0]; rep[0] = offset; }
+            else if (idx == 3) { offset = rep[2]; rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = offset; }
+            else { offset = rep[0] - 1; rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = offset; }
+        }
+        if (ll > n_lit - lpos || out + ll + ml > cap || offset == 0 || offset > out + ll) { err = FQZO_E_ENTROPY; break; }
+        memcpy(dst + out, lit + lpos, ll);
+        out += ll; lpos += ll;
+        for (uint32_t k = 0; k < ml; k++) dst[out + k] = dst[out + k - offset];
+        out += ml;
+    }
+    if (!err) {
+        if (out + (n_lit - lpos) > cap) err = FQZO_E_DST_SMALL;
+        else { memcpy(dst + out, lit + lpos, n_lit - lpos); out += n_lit - lpos; }
+    }
+    free(lit);
+    return err ? err : (long)out;
+}
+
 static long decode_compressed_block(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, huf_state *hs)
 {
     if (n < 2) return FQZO_E_ENTROPY;
@@ -757,9 +1091,10 @@ static long decode_compressed_block(const uint8_t *src, size_t n, uint8_t *dst, 
             if (huf_decode_stream(p + s1 + s2 + s3, s4, dt, table_log, dst + 3 * seg, regen - 3 * seg) < 0) return FQZO_E_ENTROPY;
         }
     }
-    /* sequences section: must say 0 sequences and end the block */
-    if (lh + csize + 1 != n || src[lh + csize] != 0) return FQZO_E_ENTROPY;
-    return (long)regen;
+    /* sequences section */
+    if (lh + csize + 1 > n) return FQZO_E_ENTROPY;
+    if (src[lh + csize] == 0) return lh + csize + 1 == n ? (long)regen : FQZO_E_ENTROPY; /* 0 sequences: the literals are the block */
+    return exec_sequences(src + lh + csize, n - lh - csize, dst, regen, cap);
 }
 
 static int parse_frame_header(const uint8_t *src, size_t n, size_t *hdr_size, long *fcs, int *has_checksum)

@@ -1,0 +1,117 @@
+"""Headers-stream modelling of the FQZ-H2 profile (zstd sequences with the predefined tables; oracle/fqz_entropy.c
+hdr_chunk_model, fastqpacker_amd/csrc/fqz_hdrlz.h): an independent decoder (libzstd) accepts it, the GPU writes the same
+bytes as the oracle and reads them back on its fast path AND on the general one."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fastq_gen import make_fastq
+
+
+@pytest.fixture(scope="module")
+def fq():
+    import fastqpacker_amd as fq
+    fq.lib()
+    return fq
+
+
+def _records(headers, seed=3, L=40):
+    rng = np.random.default_rng(seed)
+    out = []
+    for h in headers:
+        seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), L).tobytes()
+        out.append(b"@" + h + b"\n" + seq + b"\n+\n" + b"I" * L + b"\n")
+    return b"".join(out)
+
+
+def _hdr_cases():
+    rng = np.random.default_rng(5)
+    yield "illumina", make_fastq(3000, seed=31, min_len=30, max_len=60)
+    yield "identical", _records([b"read"] * 5000)
+    yield "identical-long", _records([b"x" * 300] * 400)
+    yield "sra-short (more records per chunk than the model takes)", _records([b"SRR1.%d" % i for i in range(9000)])
+    yield "sra-long", _records([b"SRR1234567.%d %d length=150" % (i, i) for i in range(4000)])
+    yield "random (nothing to match)", _records([bytes(rng.integers(33, 127, int(rng.integers(1, 80)), dtype=np.uint8)).replace(b"\n", b"x") for _ in range(3000)])
+    yield "empty headers", _records([b""] * 3000)
+    yield "one symbol", _records([b"A" * int(n) for n in rng.integers(0, 50, 3000)])
+    yield "mixed lengths", _records([b"inst:%d:%s/1" % (i // 7, b"T" * int(rng.integers(0, 200))) for i in range(2500)])
+    yield "long headers (few records per chunk)", _records([b"%d|" % i + b"ACME-SEQ-9000 run=77 lane=3 " * 40 for i in range(300)])
+    yield "tail only", _records([bytes(rng.integers(65, 91, 12, dtype=np.uint8)) + b" common tail of some length" for _ in range(3000)])
+    yield "crlf", make_fastq(800, seed=32, crlf=True)
+
+
+def _hdr_stream(text):
+    recs, n = O.parse_all(text)
+    return O.split_block(text, recs, n, 0)[0][2]
+
+
+@pytest.mark.skipif(O.libzstd() is None, reason="system libzstd.so.1 not present")
+def test_oracle_headers_payload_is_zstd_and_smaller():
+    sizes = {}
+    for name, text in _hdr_cases():
+        h = _hdr_stream(text)
+        f = O.entropy_encode(h, stream=2)
+        assert O.zstd_decompress(f, len(h) + 1) == h, name
+        assert O.entropy_decode(f, len(h)) == h, name
+        plain = O.entropy_encode(h, stream=1)
+        assert len(f) <= len(plain) * 1.05 + 64, name   # (no per-block choice between the two codings: a few percent can be lost on odd data)
+        sizes[name] = (len(h), len(plain), len(f))
+    h, plain, f = sizes["illumina"]
+    assert f * 1.3 < plain                     # Illumina headers: prefix + suffix of the predecessor
+    h, plain, f = sizes["identical"]
+    assert f * 20 < h
+
+
+def test_oracle_blocks_are_independent():
+    """No match reaches in front of its 16 KiB block and the first sequence of a block never uses a repeat offset: any
+    group (= zstd frame) of the payload decodes alone."""
+    text = make_fastq(3000, seed=33, min_len=30, max_len=60)
+    h = _hdr_stream(text)
+    f = O.entropy_encode(h, stream=2)
+    idx, frames = O.payload_frames(f)
+    assert len(frames) >= 2
+    pos = 0
+    for fr in frames:
+        part = O.entropy_decode(fr)
+        assert part == h[pos:pos + len(part)]
+        pos += len(part)
+    assert pos == len(h)
+
+
+@pytest.mark.gpu
+def test_gpu_headers_match_oracle_and_round_trip(fq):
+    for name, text in _hdr_cases():
+        want = O.compress(text)
+        got = fq.compress.Compress(text)
+        assert got == want, name
+        assert fq.compress.Decompress(got) == text, name
+        os.environ["FQZ_DEC_GENERAL"] = "1"   # the general walk hands such payloads to the full zstd decoder (k_dec_lz)
+        try:
+            assert fq.compress.Decompress(got) == text, name
+        finally:
+            del os.environ["FQZ_DEC_GENERAL"]
+
+
+@pytest.mark.gpu
+def test_gpu_rejects_damaged_sequences(fq):
+    """Flipping bits inside a Sequences_Section must never pass: the content checksum of the frame catches what the
+    structure checks let through."""
+    text = make_fastq(2000, seed=34, min_len=30, max_len=60)
+    good = bytearray(fq.compress.Compress(text))
+    hdr = [int.from_bytes(good[10 + 4 * i: 14 + 4 * i], "little") for i in range(9)]
+    h_off = 10 + 36 + hdr[1] + hdr[2]          # headers payload
+    rng = np.random.default_rng(9)
+    n_fail = 0
+    for _ in range(24):
+        bad = bytearray(good)
+        at = h_off + int(rng.integers(40, hdr[3]))
+        bad[at] ^= 1 << int(rng.integers(0, 8))
+        try:
+            out = fq.compress.Decompress(bytes(bad))
+        except Exception:
+            n_fail += 1
+            continue
+        assert out == text                     # (a flip in padding bits of a bitstream can be harmless)
+    assert n_fail >= 20
