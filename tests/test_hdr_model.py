@@ -60,7 +60,7 @@ def test_oracle_headers_payload_is_zstd_and_smaller():
         sizes[name] = (len(h), len(plain), len(f))
     h, plain, f = sizes["illumina"]
     assert f * 1.3 < plain                     # Illumina headers: prefix + suffix of the predecessor
-    h, plain, f = sizes["identical"]
+    h, plain, f = sizes["identical-long"]
     assert f * 20 < h
 
 
