@@ -28,6 +28,19 @@ def Compress(fastq, opts: Options = None, ctx=None) -> bytes:
     return out[: n.value].tobytes()
 
 
+def CompressMulti(fastq, devices, opts: Options = None) -> bytes:
+    """compress.Compress with the reference's worker pool spread over several devices (compress.go:240-278): one host
+    thread + context per entry of `devices`, contiguous ranges of whole blocks, output identical to Compress."""
+    a = _as_u8(fastq)
+    cap = lib().fqz_encode_bound(a.size) + 10
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    devs = (C.c_int * len(devices))(*devices)
+    check(lib().fqz_compress_multi(devs, len(devices), a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, C.byref(n),
+                                   C.byref(opts) if opts is not None else None))
+    return out[: n.value].tobytes()
+
+
 def Decompress(fqz, opts: DecompressOptions = None, ctx=None) -> bytes:
     """compress.Decompress (compress.go:558): .fqz bytes -> FASTQ bytes (one decode; the library allocates the text)."""
     ctx = ctx or default_ctx()

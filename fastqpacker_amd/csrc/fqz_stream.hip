@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -36,6 +37,7 @@ size_t slice_bytes()
 }
 
 struct Io { // the two ends of a stream job: either plain memory (copied to / from the device directly) or callbacks
+    const uint8_t *dev_in = nullptr; size_t dev_in_n = 0, dev_in_pos = 0; // memory source, first part: already on the device (fqz_compress_multi)
     const uint8_t *mem_in = nullptr; size_t mem_in_n = 0, mem_in_pos = 0;
     fqz_read_fn rd = nullptr; void *rd_user = nullptr;
     uint8_t *mem_out = nullptr; size_t mem_out_cap = 0; bool count_only = false;
@@ -152,7 +154,13 @@ void drain_loop(Pipe &P, Io &io, int device)
 // ===========================================================================
 // compress.Compress
 // ===========================================================================
-static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts)
+// One shard of a multi-device job (fqz_compress_multi): the encoding is the file's, decided by the shard that holds block 0
+struct ShardRole {
+    int explicit_enc = -1;                 // >= 0: encode with this FQZ_ENCODING_*, write no file header
+    std::function<void(int)> on_enc;       // the shard with block 0 reports what it detected
+};
+
+static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts, const ShardRole *role = nullptr)
 {
     fqz_options o = {FQZ_DEFAULT_BLOCK_SIZE, 0};                       // compress.go:126-128 (nil opts)
     if (opts) o = *opts;
@@ -175,10 +183,14 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts)
             if (s.d_new.ensure(slice + 64)) { P.fail(FQZ_E_NOMEM); return; }
             size_t n = 0;
             if (io.mem_in || !io.rd) { // memory source: straight over the link
-                n = io.mem_in_n - io.mem_in_pos < slice ? io.mem_in_n - io.mem_in_pos : slice;
-                if (n && hipMemcpy(s.d_new.p, io.mem_in + io.mem_in_pos, n, hipMemcpyHostToDevice) != hipSuccess) { P.fail(FQZ_E_HIP); return; }
-                io.mem_in_pos += n;
-                s.eof = io.mem_in_pos == io.mem_in_n;
+                const size_t nd = io.dev_in_n - io.dev_in_pos < slice ? io.dev_in_n - io.dev_in_pos : slice; // resident part first
+                if (nd && hipMemcpy(s.d_new.p, io.dev_in + io.dev_in_pos, nd, hipMemcpyDeviceToDevice) != hipSuccess) { P.fail(FQZ_E_HIP); return; }
+                io.dev_in_pos += nd;
+                const size_t nh = io.mem_in_n - io.mem_in_pos < slice - nd ? io.mem_in_n - io.mem_in_pos : slice - nd;
+                if (nh && hipMemcpy(s.d_new.as<uint8_t>() + nd, io.mem_in + io.mem_in_pos, nh, hipMemcpyHostToDevice) != hipSuccess) { P.fail(FQZ_E_HIP); return; }
+                io.mem_in_pos += nh;
+                n = nd + nh;
+                s.eof = io.mem_in_pos == io.mem_in_n && io.dev_in_pos == io.dev_in_n;
             } else {
                 if (s.h_in.ensure(slice)) { P.fail(FQZ_E_NOMEM); return; }
                 long r = io.read_full(s.h_in.as<uint8_t>(), slice);
@@ -199,6 +211,7 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts)
     int enc = FQZ_DETECT_ENCODING;                                      // decided on the first batch (compress.go:146-154)
     uint8_t flags = 0;
     bool first = true;
+    if (role && role->explicit_enc >= 0) { enc = role->explicit_enc; first = false; }
     const uint8_t *carry = nullptr; // lives in the previous lane's text buffer
     size_t carry_len = 0;
     long k = 0;
@@ -233,6 +246,7 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts)
             fqz_write_file_header(&fh, s.header);
             s.header_first = true;
             first = false;
+            if (role && role->on_enc) role->on_enc(enc);
         }
         s.d_res = lane->d_out.as<uint8_t>();
         s.res_len = res.out_len;
@@ -493,4 +507,186 @@ extern "C" int fqz_decompress_file(fqz_ctx *ctx, const char *in_path, const char
     if (fi != stdin) fclose(fi);
     if (fo != stdout && fclose(fo) && !rc) rc = FQZ_E_IO;
     return rc;
+}
+
+// ===========================================================================
+// compress.Compress over several devices: the worker pool of the reference (W goroutines pulling batches, ordered
+// collector; compress.go:240-278, 365-403) becomes one host thread + one context per device.  Blocks are independent and
+// the file is their concatenation, so every device gets a contiguous range of whole blocks:
+//   phase A  each thread brings its byte range of the text onto its device and counts the lines in it
+//   host     prefix sum of the counts -> for every device the first line that starts a block (a multiple of
+//            4 x 100 000 lines: the parser takes exactly four lines per record, fqparser/parser.go:136-184) at or behind
+//            its range; the tile that holds it is fetched and searched on the host
+//   phase B  each thread runs the streaming pipeline above on its shard, fed from the resident range (plus, from the
+//            host, the part of its last block that lies in the next range); the shard with block 0 detects the quality
+//            encoding, the others wait for it (FlagPhred64 is a property of the file, compress.go:146-164)
+//   host     the shards' outputs are concatenated in order (sizes are on the host after every finish)
+// ===========================================================================
+namespace {
+const uint32_t MC_TILE = 1u << 16;
+__global__ __launch_bounds__(256) void k_multi_count(const uint8_t *text, size_t n, uint32_t *counts)
+{
+    __shared__ uint32_t sh[4];
+    const size_t base = (size_t)blockIdx.x * MC_TILE;
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x * 16; i < MC_TILE; i += 256 * 16) {
+        const size_t off = base + i;
+        if (off + 16 <= n) {
+            const uint4 v = *(const uint4 *)(text + off);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int k = 0; k < 4; k++) {
+                const uint32_t x = w[k] ^ 0x0A0A0A0Au;
+                c += __popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u);
+            }
+        } else {
+            for (size_t q = off; q < n && q < off + 16; q++) c += text[q] == '\n';
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+struct Shard {
+    int device = 0;
+    fqz_ctx *ctx = nullptr;
+    size_t r0 = 0, r1 = 0;             // byte range resident on the device
+    DevBuf text, counts;
+    std::vector<uint32_t> h_counts;    // newlines per MC_TILE of the range
+    unsigned long long lines = 0;
+    size_t a = 0, b = 0;               // the shard: text bytes [a, b), whole blocks
+    std::vector<uint8_t> out;
+    int rc = 0;
+};
+
+int grow_vec(void *u, const uint8_t *src, size_t n)
+{
+    std::vector<uint8_t> *v = (std::vector<uint8_t> *)u;
+    try { v->insert(v->end(), src, src + n); } catch (...) { return 1; }
+    return 0;
+}
+} // namespace
+
+extern "C" int fqz_compress_multi(const int *devices, int n_devices, const uint8_t *fastq, size_t n, uint8_t *out, size_t out_cap, size_t *out_len,
+                                  const fqz_options *opts)
+{
+    if (!devices || n_devices < 1 || n_devices > 64 || (!fastq && n) || !out || !out_len) return FQZ_E_ARG;
+    *out_len = 0;
+    const uint32_t rpb = FQZ_DEFAULT_BLOCK_SIZE;
+    const int N = n_devices;
+    std::vector<Shard> sh((size_t)N);
+    // byte ranges: equal parts, cut at multiples of the counting tile
+    for (int d = 0; d < N; d++) {
+        sh[d].device = devices[d];
+        sh[d].r0 = d ? sh[d - 1].r1 : 0;
+        size_t r1 = d + 1 == N ? n : (size_t)((unsigned long long)n * (unsigned)(d + 1) / (unsigned)N) / MC_TILE * MC_TILE;
+        sh[d].r1 = r1 < sh[d].r0 ? sh[d].r0 : r1;
+    }
+    // ---- phase A
+    {
+        std::vector<std::thread> th;
+        for (int d = 0; d < N; d++)
+            th.emplace_back([&, d] {
+                Shard &s = sh[d];
+                if (hipSetDevice(s.device) != hipSuccess) { s.rc = FQZ_E_HIP; return; }
+                if ((s.rc = fqz_ctx_create(s.device, &s.ctx))) return;
+                const size_t len = s.r1 - s.r0, tiles = (len + MC_TILE - 1) / MC_TILE;
+                if ((s.rc = s.text.ensure(len + 64)) || (s.rc = s.counts.ensure(4 * (tiles + 1)))) return;
+                const size_t step = (size_t)256 << 20;
+                for (size_t o = 0; o < len; o += step) { // (pageable source: the copy of one slice overlaps the count of the one before)
+                    const size_t m = len - o < step ? len - o : step;
+                    if (hipMemcpyAsync(s.text.as<uint8_t>() + o, fastq + s.r0 + o, m, hipMemcpyHostToDevice, s.ctx->stream) != hipSuccess) { s.rc = FQZ_E_HIP; return; }
+                }
+                if (tiles) hipLaunchKernelGGL(k_multi_count, dim3((unsigned)tiles), dim3(256), 0, s.ctx->stream, s.text.as<uint8_t>(), len, s.counts.as<uint32_t>());
+                s.h_counts.resize(tiles);
+                if (tiles && hipMemcpyAsync(s.h_counts.data(), s.counts.p, 4 * tiles, hipMemcpyDeviceToHost, s.ctx->stream) != hipSuccess) { s.rc = FQZ_E_HIP; return; }
+                if (hipStreamSynchronize(s.ctx->stream) != hipSuccess) { s.rc = FQZ_E_HIP; return; }
+                for (uint32_t c : s.h_counts) s.lines += c;
+            });
+        for (auto &t : th) t.join();
+    }
+    int rc = 0;
+    for (int d = 0; d < N && !rc; d++) rc = sh[d].rc;
+    // ---- shard starts: the first block boundary at or behind the start of every range
+    if (!rc) {
+        std::vector<unsigned long long> L((size_t)N + 1, 0); // lines in front of range d
+        for (int d = 0; d < N; d++) L[d + 1] = L[d] + sh[d].lines;
+        const unsigned long long per_block = 4ull * rpb;
+        size_t prev = 0;
+        for (int d = 0; d < N && !rc; d++) {
+            size_t a = 0;
+            if (d) {
+                const unsigned long long T = (L[d] + per_block - 1) / per_block * per_block; // line T starts a block
+                if (T == 0) a = 0;
+                else if (T > L[N]) a = n;
+                else { // one byte behind newline number T - 1 (0-based), which lies in the range e with L[e] <= T - 1 < L[e + 1]
+                    int e = d;
+                    while (e + 1 < N && L[e + 1] <= T - 1) e++;
+                    unsigned long long j = T - 1 - L[e];
+                    size_t tile = 0;
+                    while (tile < sh[e].h_counts.size() && j >= sh[e].h_counts[tile]) { j -= sh[e].h_counts[tile]; tile++; }
+                    if (tile >= sh[e].h_counts.size()) { rc = FQZ_E_HIP; break; } // (cannot happen: the counts say the newline is there)
+                    const size_t t0 = tile * (size_t)MC_TILE, tl = sh[e].r1 - sh[e].r0 - t0 < MC_TILE ? sh[e].r1 - sh[e].r0 - t0 : MC_TILE;
+                    const uint8_t *p = fastq + sh[e].r0 + t0; // (the text is on the host as well: search the tile there)
+                    size_t q = 0;
+                    for (; q < tl; q++)
+                        if (p[q] == '\n' && j-- == 0) break;
+                    a = sh[e].r0 + t0 + q + 1;
+                }
+                if (a < prev) a = prev;
+            }
+            sh[d].a = a;
+            prev = a;
+        }
+        for (int d = 0; d < N; d++) sh[d].b = d + 1 < N ? sh[d + 1].a : n;
+    }
+    // ---- phase B
+    if (!rc) {
+        std::mutex mu;
+        std::condition_variable cv;
+        int file_enc = -1; // -1 not known yet, -2 the first shard failed
+        std::vector<std::thread> th;
+        for (int d = 0; d < N; d++)
+            th.emplace_back([&, d] {
+                Shard &s = sh[d];
+                (void)hipSetDevice(s.device);
+                ShardRole role;
+                if (d == 0) role.on_enc = [&](int e) { std::lock_guard<std::mutex> g(mu); file_enc = e; cv.notify_all(); };
+                else {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return file_enc != -1; });
+                    if (file_enc < 0) { s.rc = 0; return; } // (the error is the first shard's)
+                    role.explicit_enc = file_enc;
+                    if (s.a >= s.b) return; // nothing left for this device
+                }
+                Io io;
+                static const uint8_t nothing = 0;
+                // the resident part of [a, b), then what lies behind the range on the host
+                if (s.a < s.r0) { s.rc = FQZ_E_ARG; return; } // (starts are never in front of their range)
+                const size_t dev_end = s.b < s.r1 ? s.b : s.r1, ha = s.a > s.r1 ? s.a : s.r1;
+                if (s.a < dev_end) { io.dev_in = s.text.as<uint8_t>() + (s.a - s.r0); io.dev_in_n = dev_end - s.a; }
+                io.mem_in = s.b > ha ? fastq + ha : &nothing;
+                io.mem_in_n = s.b > ha ? s.b - ha : 0;
+                io.wr = grow_vec; io.wr_user = &s.out;
+                s.rc = compress_job(s.ctx, io, opts, &role);
+                if (d == 0) { std::lock_guard<std::mutex> g(mu); if (file_enc == -1) { file_enc = -2; cv.notify_all(); } }
+            });
+        for (auto &t : th) t.join();
+        for (int d = 0; d < N && !rc; d++) rc = sh[d].rc; // the error of the earliest shard, like the ordered collector
+    }
+    for (int d = 0; d < N; d++)
+        if (sh[d].ctx) {
+            (void)hipSetDevice(sh[d].device);
+            sh[d].text.release(); sh[d].counts.release();
+            fqz_ctx_destroy(sh[d].ctx);
+        }
+    if (rc) return rc;
+    size_t total = 0;
+    for (int d = 0; d < N; d++) total += sh[d].out.size();
+    if (total > out_cap) return FQZ_E_DST_SMALL;
+    size_t pos = 0;
+    for (int d = 0; d < N; d++) { if (!sh[d].out.empty()) memcpy(out + pos, sh[d].out.data(), sh[d].out.size()); pos += sh[d].out.size(); }
+    *out_len = total;
+    return FQZ_OK;
 }

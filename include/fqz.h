@@ -231,6 +231,11 @@ int fqz_decompress_stream(fqz_ctx *ctx, fqz_read_fn read, void *read_user, fqz_w
 /* compress.Decompress into a buffer the library allocates (one decode, no sizing pass); release it with fqz_buffer_free. */
 int fqz_decompress_alloc(fqz_ctx *ctx, const uint8_t *fqz, size_t n, uint8_t **out, size_t *out_len, const fqz_decompress_options *opts);
 void fqz_buffer_free(uint8_t *p);
+/* compress.Compress over several devices: the reference's worker pool + ordered collector (compress.go:240-278, 365-403)
+ * as one host thread and one context per entry of devices[] (an entry may repeat).  Every device encodes a contiguous
+ * range of whole 100 000-record blocks; the output is byte-identical to fqz_compress on one device. */
+int fqz_compress_multi(const int *devices, int n_devices, const uint8_t *fastq, size_t n, uint8_t *out, size_t out_cap, size_t *out_len,
+                       const fqz_options *opts);
 /* File-to-file forms used by the fqpack CLI driver (cmd/fqpack/main.go:190-203); stream through the same pipeline. */
 int fqz_compress_file(fqz_ctx *ctx, const char *in_path, const char *out_path, const fqz_options *opts);
 int fqz_decompress_file(fqz_ctx *ctx, const char *in_path, const char *out_path, const fqz_decompress_options *opts);

@@ -128,3 +128,28 @@ def test_memory_stays_bounded_for_a_large_stream(fq, tmp_path):
                 break
     grown_mb = max(0, after - before) / 1024
     assert grown_mb < 0.5 * size / 1e6, "peak RSS grew by %.0f MB for a %.0f MB file" % (grown_mb, size / 1e6)
+
+
+def test_compress_multi_is_identical_to_one_device(fq):
+    """fqz_compress_multi with the one device of the box listed two and three times: every 'device' encodes a contiguous
+    range of whole 100 000-record blocks (cut by line count), the file is the same as the single-device one."""
+    text, n = fq.compress.synth_fastq(450_017, min_len=35, max_len=90, n_permille=20)   # 5 blocks, the last one partial
+    text = text.tobytes()
+    want = fq.compress.Compress(text)
+    for devs in ([0], [0, 0], [0, 0, 0], [0] * 7):                                    # (7: more shards than blocks -> empty shards)
+        assert fq.compress.CompressMulti(text, devs) == want, devs
+    small = text[: 2_000_000]                                                           # less than one block: the first shard takes it all
+    small = small[: small.rfind(b"\n@") + 1]
+    assert fq.compress.CompressMulti(small, [0, 0]) == fq.compress.Compress(small)
+    assert fq.compress.CompressMulti(b"", [0, 0]) == fq.compress.Compress(b"")
+    # Phred+64 decided by the first shard, applied by the others
+    t64, _ = fq.compress.synth_fastq(250_000, min_len=40, max_len=60, phred=64)
+    t64 = t64.tobytes()
+    w64 = fq.compress.Compress(t64)
+    assert w64[9] & 2 and fq.compress.CompressMulti(t64, [0, 0]) == w64
+    # a parse error in a later shard is reported
+    bad = bytearray(text)
+    at = text.rfind(b"\n+\n")
+    bad[at + 1] = ord("-")
+    with pytest.raises(Exception):
+        fq.compress.CompressMulti(bytes(bad), [0, 0])
