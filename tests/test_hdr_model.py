@@ -86,6 +86,7 @@ def test_gpu_headers_match_oracle_and_round_trip(fq):
         want = O.compress(text)
         got = fq.compress.Compress(text)
         assert got == want, name
+        text = text.replace(b"\r\n", b"\n")     # (line ends are not kept: parser.go readLine strips '\r')
         assert fq.compress.Decompress(got) == text, name
         os.environ["FQZ_DEC_GENERAL"] = "1"   # the general walk hands such payloads to the full zstd decoder (k_dec_lz)
         try:
