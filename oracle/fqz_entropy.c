@@ -30,6 +30,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 #define HUF_MAX_BITS 11
 #define FSE_W_MAXLOG 6
@@ -397,11 +398,12 @@ static inline int ml_code(uint32_t mlb) /* mlb = match length - 3 */
 }
 
 /* Sequences_Section of n > 0 sequences: count, modes byte (all Predefined), bitstream (ZSTD_encodeSequences order) */
+static fse_ct LL, ML, OF; /* compression tables of the predefined distributions */
+static void hdr_ct_init(void) { fse_build_ct(&LL, LL_NORM, 36, 6); fse_build_ct(&ML, ML_NORM, 53, 6); fse_build_ct(&OF, OF_NORM, 29, 5); }
 static size_t hdr_write_sequences(const hseq *sq, uint32_t n, uint8_t *dst)
 {
-    static fse_ct LL, ML, OF;
-    static int ready = 0;
-    if (!ready) { fse_build_ct(&LL, LL_NORM, 36, 6); fse_build_ct(&ML, ML_NORM, 53, 6); fse_build_ct(&OF, OF_NORM, 29, 5); ready = 1; }
+    static pthread_once_t once = PTHREAD_ONCE_INIT; /* (the pipeline's workers call this concurrently) */
+    pthread_once(&once, hdr_ct_init);
     uint8_t *op = dst;
     if (n < 128) *op++ = (uint8_t)n;
     else { *op++ = (uint8_t)((n >> 8) + 128); *op++ = (uint8_t)n; } /* n < 0x7F00 */
@@ -977,11 +979,12 @@ static void fse_build_dt(fse_de *dt, const short *norm, int nsym, int log)
         dt[u].base = (uint16_t)((ns << dt[u].nb) - (uint32_t)size);
     }
 }
+static fse_de LLD[64], MLD[64], OFD[32]; /* decoding tables of the predefined distributions */
+static void hdr_dt_init(void) { fse_build_dt(LLD, LL_NORM, 36, 6); fse_build_dt(MLD, ML_NORM, 53, 6); fse_build_dt(OFD, OF_NORM, 29, 5); }
 static long exec_sequences(const uint8_t *sec, size_t n, uint8_t *dst, size_t n_lit, size_t cap)
 {
-    static fse_de LLD[64], MLD[64], OFD[32];
-    static int ready = 0;
-    if (!ready) { fse_build_dt(LLD, LL_NORM, 36, 6); fse_build_dt(MLD, ML_NORM, 53, 6); fse_build_dt(OFD, OF_NORM, 29, 5); ready = 1; }
+    static pthread_once_t once = PTHREAD_ONCE_INIT;
+    pthread_once(&once, hdr_dt_init);
     size_t p = 0;
     uint32_t nseq = sec[p++];
     if (nseq >= 128) { if (p >= n) return FQZO_E_ENTROPY; if (nseq == 255) return FQZO_E_ENTROPY; nseq = ((nseq - 128) << 8) + sec[p++]; }
@@ -1005,15 +1008,13 @@ static long exec_sequences(const uint8_t *sec, size_t n, uint8_t *dst, size_t n_
             st_ml = MLD[st_ml].base + br_read(&br, MLD[st_ml].nb);
             st_of = OFD[st_of].base + br_read(&br, OFD[st_of].nb);
         }
+        /* FQZ-H2 blocks are self-contained: an explicit offset, or "the offset of the previous sequence of this block"
+         * (Offset_Value 1 with literals).  Anything else needs the offset history of earlier blocks: not this subset */
         uint32_t offset;
-        if (of_val > 3) { offset = of_val - 3; rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = offset; }
-        else {
-            const uint32_t idx = of_val + (ll == 0 ? 1u : 0u);
-            if (idx == 1) offset = rep[0];
-            else if (idx == 2) { offset = rep[1]; rep[1] = rep[0]; rep[0] = offset; }
-            else if (idx == 3) { offset = rep[2]; rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = offset; }
-            else { offset = rep[0] - 1; rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = offset; }
-        }
+        if (of_val > 3) offset = of_val - 3;
+        else if (of_val == 1 && ll > 0 && i > 0) offset = rep[0];
+        else { err = FQZO_E_ENTROPY; break; }
+        rep[0] = offset;
         if (ll > n_lit - lpos || out + ll + ml > cap || offset == 0 || offset > out + ll) { err = FQZO_E_ENTROPY; break; }
         memcpy(dst + out, lit + lpos, ll);
         out += ll; lpos += ll;
