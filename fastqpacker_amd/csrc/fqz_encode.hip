@@ -893,12 +893,24 @@ __global__ __launch_bounds__(256) void k_hdr_model(const EncInfo *info, const Bl
     hdr_model_chunk(S, arena + p->a_off[S_HDR], Eh, p->rec0, p->nrec, c0, mk, hseq + (size_t)o * HDR_MAX_SEQ, hlit + (size_t)o * FQZ_CHUNK, &side[o]);
 }
 
-__global__ __launch_bounds__(64) void k_hdr_seq(const EncInfo *info, uint32_t hcap, const uint2 *hseq, uint8_t *hsec, HdrSide *side)
+__global__ __launch_bounds__(64) void k_hdr_seq1(const EncInfo *info, uint32_t hcap, const uint2 *hseq, uint32_t *hst, HdrSide *side)
 {
-    const uint32_t o = blockIdx.x * 64 + threadIdx.x;
+    __shared__ HdrChainLds T;
+    const uint32_t lane = threadIdx.x, o = blockIdx.x * 16 + (lane >> 2), c = lane & 3;
+    const uint32_t nh = info->n_hchunks < hcap ? info->n_hchunks : hcap;
+    if (blockIdx.x * 16 >= nh) return;
+    hdr_chain_tables(T);
+    const uint32_t nseq = o < nh ? side[o].nseq : 0u;
+    hdr_seq_chains(T, hseq + (size_t)o * HDR_MAX_SEQ, nseq, hst + (size_t)o * HDR_MAX_SEQ, &side[o], c, o < nh && nseq != 0);
+}
+
+__global__ __launch_bounds__(64) void k_hdr_seq2(const EncInfo *info, uint32_t hcap, const uint2 *hseq, const uint32_t *hst, uint8_t *hsec, HdrSide *side)
+{
+    __shared__ __attribute__((aligned(16))) HdrPackLds S;
+    const uint32_t o = blockIdx.x;
     if (o >= info->n_hchunks || o >= hcap) return;
     const uint32_t nseq = side[o].nseq;
-    if (nseq) hdr_encode_sequences(hseq + (size_t)o * HDR_MAX_SEQ, nseq, hsec + (size_t)o * HDR_SEQ_CAP, &side[o]);
+    if (nseq) hdr_seq_pack(S, hseq + (size_t)o * HDR_MAX_SEQ, nseq, hst + (size_t)o * HDR_MAX_SEQ, hsec + (size_t)o * HDR_SEQ_CAP, &side[o]);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_entropy_hdr(const EncInfo *info, const uint4 *hmap, const uint8_t *arena, uint8_t *slots, uint32_t *csize,
@@ -1287,9 +1299,10 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     if (e.hcap_need > hcap && e.n_bytes == n_bytes) hcap = e.hcap_need;
     if ((size_t)hcap > main_cap) hcap = (uint32_t)main_cap;
     e.hcap = hcap;
-    if ((rc = e.hside.ensure((size_t)hcap * (8ull * HDR_MAX_SEQ + FQZ_CHUNK + HDR_SEQ_CAP + sizeof(HdrSide) + 4) + 256))) return rc;
+    if ((rc = e.hside.ensure((size_t)hcap * (12ull * HDR_MAX_SEQ + FQZ_CHUNK + HDR_SEQ_CAP + sizeof(HdrSide) + 4) + 256))) return rc;
     uint2 *hseq = e.hside.as<uint2>();
-    uint8_t *hlit = (uint8_t *)(hseq + (size_t)hcap * HDR_MAX_SEQ), *hsec = hlit + (size_t)hcap * FQZ_CHUNK;
+    uint32_t *hst = (uint32_t *)(hseq + (size_t)hcap * HDR_MAX_SEQ);
+    uint8_t *hlit = (uint8_t *)(hst + (size_t)hcap * HDR_MAX_SEQ), *hsec = hlit + (size_t)hcap * FQZ_CHUNK;
     HdrSide *hside = (HdrSide *)(hsec + (size_t)hcap * HDR_SEQ_CAP);
     uint32_t *hlist = (uint32_t *)(hside + hcap);
     PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), hmap, e.xmap.as<uint4>(), group_cap,
@@ -1306,7 +1319,8 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     // the headers chain (model -> sequences -> entropy over the literals) runs beside the entropy coder of the other streams too
     const uint32_t hgroup_cap = hcap / FQZ_GROUP + e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + e.block_cap + 8 : group_cap;
     PROF(ctx, e.side, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, e.side, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside));
-    PROF(ctx, e.side, "k_hdr_seq", hipLaunchKernelGGL(k_hdr_seq, dim3((hcap + 63) / 64), dim3(64), 0, e.side, info, hcap, hseq, hsec, hside));
+    PROF(ctx, e.side, "k_hdr_seq1", hipLaunchKernelGGL(k_hdr_seq1, dim3((hcap + 15) / 16), dim3(64), 0, e.side, info, hcap, hseq, hst, hside));
+    PROF(ctx, e.side, "k_hdr_seq2", hipLaunchKernelGGL(k_hdr_seq2, dim3(hcap), dim3(64), 0, e.side, info, hcap, hseq, hst, hsec, hside));
     PROF(ctx, e.side, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, e.side, info, hmap, arena, slots, csize, hord, hcap, hlit, hsec, hside));
     PROF(ctx, e.side, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, e.side, info, e.xmap.as<uint4>(), arena, npos, xsum));
     HIP_TRY(hipEventRecord(e.ev_join, e.side));

@@ -84,42 +84,41 @@ __constant__ const uint8_t c_hml_code[128] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 
 // ---------------------------------------------------------------------------------------------
 // k_hdr_model: one workgroup per headers chunk -> its sequences (hseq: ll | ml << 16, offset) and its literals (hlit)
 // ---------------------------------------------------------------------------------------------
+#define HDR_TPAD 16u // bytes in front of the chunk in LDS: the backward compares read 8 bytes at a time
 struct HdrModelLds {
-    uint8_t text[FQZ_CHUNK + 16];
-    uint16_t s[HDR_MAX_SEQ / 2 + 2], len[HDR_MAX_SEQ / 2 + 2];   // record starts (chunk-relative) and lengths
+    uint8_t text[HDR_TPAD + FQZ_CHUNK + 16];
+    uint16_t e[HDR_MAX_SEQ / 2 + 2];                             // record starts, chunk-relative (e[n_in] = end of the last record)
     uint16_t hs[HDR_MAX_SEQ / 2 + 2], hl[HDR_MAX_SEQ / 2 + 2], tl[HDR_MAX_SEQ / 2 + 2]; // head start / length, tail length
-    uint32_t sh[12];
-    uint32_t carry[3];      // sequences, matched bytes, end of the last match so far
+    uint32_t sh[8];
+    uint32_t carry[2];      // sequences << 16 | matched bytes; end of the last match so far
     uint32_t q_n;           // long literal runs waiting for a cooperative copy
     uint32_t q[64][3];      // {source (chunk-relative), destination (literal offset), bytes}
-    uint32_t first, n_in;
 };
+__device__ __forceinline__ unsigned long long hdr_ld64(const uint8_t *p) { unsigned long long v; __builtin_memcpy(&v, p, 8); return v; }
 
-// exclusive scan of one value per thread over the 256-thread workgroup with op = + or max; sh: 4 words; *total = reduction
-template <bool MAX>
-__device__ __forceinline__ uint32_t hdr_block_scan(uint32_t v, uint32_t *sh, uint32_t *total)
+// exclusive scans over the 256-thread workgroup: a = running sum, m = running maximum; totals in *ta, *tm.  sh: 8 words
+__device__ __forceinline__ void hdr_scan2(uint32_t a, uint32_t m, uint32_t *sh, uint32_t *ex_a, uint32_t *ex_m, uint32_t *ta, uint32_t *tm)
 {
     const uint32_t l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t incl = v;
+    uint32_t ia = a, im = m;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d, WAVE);
-        if (l >= (uint32_t)d) incl = MAX ? (t > incl ? t : incl) : incl + t;
+        const uint32_t xa = __shfl_up(ia, d, WAVE), xm = __shfl_up(im, d, WAVE);
+        if (l >= (uint32_t)d) { ia += xa; im = xm > im ? xm : im; }
     }
-    uint32_t excl = __shfl_up(incl, 1, WAVE);
-    if (l == 0) excl = 0;
+    uint32_t ea = __shfl_up(ia, 1, WAVE), em = __shfl_up(im, 1, WAVE);
+    if (l == 0) { ea = 0; em = 0; }
+    __syncthreads(); // (the previous use of sh)
+    if (l == 63) { sh[w] = ia; sh[4 + w] = im; }
     __syncthreads();
-    if (l == 63) sh[w] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
+    uint32_t ba = 0, bm = 0, sa = 0, sm = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
-        const uint32_t x = sh[k];
-        if (k < w) base = MAX ? (x > base ? x : base) : base + x;
-        tot = MAX ? (x > tot ? x : tot) : tot + x;
+        const uint32_t xa = sh[k], xm = sh[4 + k];
+        if (k < w) { ba += xa; bm = xm > bm ? xm : bm; }
+        sa += xa; sm = xm > sm ? xm : sm;
     }
-    *total = tot;
-    return MAX ? (base > excl ? base : excl) : base + excl;
+    *ex_a = ba + ea; *ex_m = bm > em ? bm : em; *ta = sa; *tm = sm;
 }
 
 __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stream, const uint32_t *__restrict__ Eh, uint32_t rec0, uint32_t nrec,
@@ -127,41 +126,69 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
 {
     const uint32_t t = threadIdx.x;
     const uint32_t base_e = Eh[rec0], c1 = c0 + mk;
-    if (t == 0) {
-        // records that lie wholly inside [c0, c1): the first one that starts at or behind c0 ... the last one that ends at or before c1
-        uint32_t lo = 0, hi = nrec;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (Eh[rec0 + mid] - base_e < c0) lo = mid + 1; else hi = mid; }
-        const uint32_t first = lo;
-        uint32_t lo2 = first, hi2 = nrec; // first record index whose END lies behind c1
-        while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (Eh[rec0 + mid + 1] - base_e <= c1) lo2 = mid + 1; else hi2 = mid; }
-        uint32_t n_in = lo2 - first;
-        if (2 * n_in > HDR_MAX_SEQ) n_in = 0;
-        S.first = first; S.n_in = n_in;
-        S.carry[0] = S.carry[1] = S.carry[2] = 0;
-        S.q_n = 0;
+    uint8_t *const text = S.text + HDR_TPAD;
+    for (uint32_t i = t * 16; i < mk; i += 256 * 16) *(uint4 *)&text[i] = load_u128_unaligned(stream + c0 + i); // (in flight during the search)
+    // ---- the records that lie wholly inside [c0, c1): first = #records that start before c0, last1 = #records that end at or
+    //      before c1; two-level search, 256 probes a level (the record table is a sorted array in global memory)
+    const uint32_t seg = (nrec + 255) / 256;
+    uint32_t first, last1;
+    {
+        const uint32_t i1 = t * seg;
+        const uint32_t v = i1 < nrec ? Eh[rec0 + i1] - base_e : 0xFFFFFFFFu, v2 = i1 < nrec ? Eh[rec0 + i1 + 1] - base_e : 0xFFFFFFFFu;
+        const uint32_t j = (uint32_t)__syncthreads_count(v < c0), j2 = (uint32_t)__syncthreads_count(v2 <= c1); // segments that begin with a hit
+        uint32_t hit = 0, hit2 = 0;
+        for (uint32_t u = t; u < seg; u += 256) { // inside the last such segment
+            if (j) { const uint32_t r = (j - 1) * seg + u; hit += r < nrec && Eh[rec0 + r] - base_e < c0; }
+            if (j2) { const uint32_t r = (j2 - 1) * seg + u; hit2 += r < nrec && Eh[rec0 + r + 1] - base_e <= c1; }
+        }
+        uint32_t h1 = 0, h2 = 0;
+        for (uint32_t q = 0; q < 32; q++) { // (seg <= 2^32 / 256: a count per thread of at most seg / 256 + 1; summed bit by bit)
+            h1 += (uint32_t)__syncthreads_count((hit >> q) & 1u) << q;
+            h2 += (uint32_t)__syncthreads_count((hit2 >> q) & 1u) << q;
+            if (!__syncthreads_or((hit >> (q + 1)) | (hit2 >> (q + 1)))) break;
+        }
+        first = j ? (j - 1) * seg + h1 : 0;
+        last1 = j2 ? (j2 - 1) * seg + h2 : 0;
     }
-    for (uint32_t i = t * 16; i < mk; i += 256 * 16) *(uint4 *)&S.text[i] = load_u128_unaligned(stream + c0 + i); // (the arena is padded: whole rows)
+    uint32_t n_in = last1 > first ? last1 - first : 0;
+    if (2 * n_in > HDR_MAX_SEQ) n_in = 0;
+    if (n_in < 2) { if (t == 0) { side->nseq = 0; side->n_lit = mk; side->sec_len = 0; side->pad = 0; } return; }
+    for (uint32_t k = t; k <= n_in; k += 256) S.e[k] = (uint16_t)(Eh[rec0 + first + k] - base_e - c0);
+    if (t == 0) { S.carry[0] = S.carry[1] = 0; S.q_n = 0; }
+    if (t < 4) ((uint32_t *)S.text)[t] = 0;
     __syncthreads();
-    const uint32_t first = S.first, n_in = S.n_in;
-    if (n_in < 2) { if (t == 0) { side->nseq = 0; side->n_lit = mk; side->sec_len = 0; } return; }
-    // ---- head and tail of every record against its predecessor (a lane per record)
+    // ---- head and tail of every record against its predecessor (a lane per record, 8 bytes per compare)
     for (uint32_t k = t; k < n_in; k += 256) {
-        const uint32_t s = Eh[rec0 + first + k] - base_e - c0, e = Eh[rec0 + first + k + 1] - base_e - c0, len = e - s;
-        uint32_t h_start = s, h_len = 0, tail = 0;
+        uint32_t h_start = S.e[k], h_len = 0, tail = 0;
         if (k) {
-            const uint32_t ps = Eh[rec0 + first + k - 1] - base_e - c0, plen = s - ps;
+            const uint32_t s = S.e[k], e = S.e[k + 1], len = e - s, ps = S.e[k - 1], plen = s - ps;
             const uint32_t lim = len < plen ? len : plen;
-            while (h_len < lim && S.text[s + h_len] == S.text[ps + h_len]) h_len++;
+            auto prefix = [&](uint32_t from) { // common prefix of the two records from byte `from` on, at most lim - from
+                uint32_t n = 0;
+                const uint32_t room = lim - from;
+                while (n < room) {
+                    const unsigned long long x = hdr_ld64(text + s + from + n) ^ hdr_ld64(text + ps + from + n);
+                    if (x) { n += (uint32_t)__builtin_ctzll(x) >> 3; break; }
+                    n += 8;
+                }
+                return n < room ? n : room;
+            };
+            h_len = prefix(0);
             if (h_len < HDR_MIN_MATCH) { // behind the length prefixes
-                h_start = s + 2; h_len = 0;
-                while (2 + h_len < lim && S.text[s + 2 + h_len] == S.text[ps + 2 + h_len]) h_len++;
+                h_start = s + 2;
+                h_len = lim > 2 ? prefix(2) : 0;
                 if (h_len < HDR_MIN_MATCH) { h_start = s; h_len = 0; }
             }
             const uint32_t used = h_len ? (h_start + h_len) - s : 0;
             const uint32_t tlim = len - used < plen ? len - used : plen;
-            while (tail < tlim && S.text[e - 1 - tail] == S.text[s - 1 - tail]) tail++;
+            while (tail < tlim) {
+                const unsigned long long x = hdr_ld64(text + e - tail - 8) ^ hdr_ld64(text + s - tail - 8);
+                if (x) { tail += (uint32_t)__builtin_clzll(x) >> 3; break; }
+                tail += 8;
+            }
+            tail = tail < tlim ? tail : tlim;
         }
-        S.s[k] = (uint16_t)s; S.len[k] = (uint16_t)len; S.hs[k] = (uint16_t)h_start; S.hl[k] = (uint16_t)h_len; S.tl[k] = (uint16_t)tail;
+        S.hs[k] = (uint16_t)h_start; S.hl[k] = (uint16_t)h_len; S.tl[k] = (uint16_t)tail;
     }
     __syncthreads();
     // ---- candidates in stream order: A_k = tail of record k-1 (+ the head of record k when they touch), B_k = head of record k alone
@@ -170,130 +197,190 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
         uint32_t posA = 0, lenA = 0, posB = 0, lenB = 0, off = 0;
         if (k <= n_in) {
             const uint32_t tail_prev = k >= 2 ? S.tl[k - 1] : 0u;
-            off = S.len[k - 1];
-            const uint32_t s_k = k < n_in ? S.s[k] : 0u, hl = k < n_in ? S.hl[k] : 0u, hs = k < n_in ? S.hs[k] : 0u;
+            off = (uint32_t)S.e[k] - S.e[k - 1];
+            const uint32_t s_k = S.e[k], hl = k < n_in ? S.hl[k] : 0u, hs = k < n_in ? S.hs[k] : 0u;
             const bool merged = tail_prev && hl && hs == s_k;
-            if (tail_prev) { posA = (uint32_t)S.s[k - 1] + S.len[k - 1] - tail_prev; lenA = tail_prev + (merged ? hl : 0u); }
+            if (tail_prev) { posA = s_k - tail_prev; lenA = tail_prev + (merged ? hl : 0u); }
             if (hl && !merged) { posB = hs; lenB = hl; }
             if (lenA < HDR_MIN_MATCH) lenA = 0;
             if (lenB < HDR_MIN_MATCH) lenB = 0;
         }
         const uint32_t cnt = (lenA ? 1u : 0u) + (lenB ? 1u : 0u);
         const uint32_t my_end = lenB ? posB + lenB : (lenA ? posA + lenA : 0u);
-        uint32_t tot_c, tot_m, tot_e;
-        const uint32_t ex_c = S.carry[0] + hdr_block_scan<false>(cnt, S.sh, &tot_c);
-        const uint32_t ex_m = S.carry[1] + hdr_block_scan<false>(lenA + lenB, S.sh + 4, &tot_m);
-        uint32_t ex_e = hdr_block_scan<true>(my_end, S.sh + 8, &tot_e);
-        ex_e = ex_e > S.carry[2] ? ex_e : S.carry[2];
+        uint32_t ex, ex_e, tot, tot_e;
+        hdr_scan2((cnt << 16) | (lenA + lenB), my_end, S.sh, &ex, &ex_e, &tot, &tot_e);
+        ex += S.carry[0];
+        ex_e = ex_e > S.carry[1] ? ex_e : S.carry[1];
+        const uint32_t ex_c = ex >> 16, ex_m = ex & 0xFFFFu;
         auto emit = [&](uint32_t idx, uint32_t prev_end, uint32_t matched_before, uint32_t pos, uint32_t ml) {
             const uint32_t ll = pos - prev_end, lit_off = prev_end - matched_before;
             hseq[idx] = make_uint2(ll | (ml << 16), off);
-            if (ll <= 32) { for (uint32_t j = 0; j < ll; j++) hlit[lit_off + j] = S.text[prev_end + j]; }
+            if (ll <= 32) { for (uint32_t j = 0; j < ll; j++) hlit[lit_off + j] = text[prev_end + j]; }
             else {
                 const uint32_t qi = atomicAdd(&S.q_n, 1u);
                 if (qi < 64) { S.q[qi][0] = prev_end; S.q[qi][1] = lit_off; S.q[qi][2] = ll; }
-                else for (uint32_t j = 0; j < ll; j++) hlit[lit_off + j] = S.text[prev_end + j];
+                else for (uint32_t j = 0; j < ll; j++) hlit[lit_off + j] = text[prev_end + j];
             }
         };
         if (lenA) emit(ex_c, ex_e, ex_m, posA, lenA);
         if (lenB) emit(ex_c + (lenA ? 1u : 0u), lenA ? posA + lenA : ex_e, ex_m + lenA, posB, lenB);
         __syncthreads();
-        if (t == 0) { S.carry[0] += tot_c; S.carry[1] += tot_m; S.carry[2] = tot_e > S.carry[2] ? tot_e : S.carry[2]; }
+        if (t == 0) { S.carry[0] += tot; S.carry[1] = tot_e > S.carry[1] ? tot_e : S.carry[1]; }
         // long literal runs of this strip: all threads copy
         const uint32_t qn = S.q_n < 64 ? S.q_n : 64;
         for (uint32_t qi = 0; qi < qn; qi++)
-            for (uint32_t j = t; j < S.q[qi][2]; j += 256) hlit[S.q[qi][1] + j] = S.text[S.q[qi][0] + j];
+            for (uint32_t j = t; j < S.q[qi][2]; j += 256) hlit[S.q[qi][1] + j] = text[S.q[qi][0] + j];
         __syncthreads();
         if (t == 0) S.q_n = 0;
-        __syncthreads();
     }
+    __syncthreads();
     // ---- the literals behind the last match
-    const uint32_t nseq = S.carry[0], matched = S.carry[1], last_end = S.carry[2];
-    if (nseq) for (uint32_t j = last_end + t; j < mk; j += 256) hlit[j - matched] = S.text[j];
-    if (t == 0) { side->nseq = nseq; side->n_lit = mk - matched; side->sec_len = 0; }
+    const uint32_t nseq = S.carry[0] >> 16, matched = S.carry[0] & 0xFFFFu, last_end = S.carry[1];
+    if (nseq) for (uint32_t j = last_end + t; j < mk; j += 256) hlit[j - matched] = text[j];
+    if (t == 0) { side->nseq = nseq; side->n_lit = mk - matched; side->sec_len = 0; side->pad = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_hdr_seq: Sequences_Section of a chunk (count, modes byte = Predefined x 3, backward bitstream in ZSTD_encodeSequences
-// order).  The FSE state chain is serial, so a LANE codes a chunk and a wave 64 chunks; every lane reads its sequences
-// eight at a time.
+// Sequences_Section of a chunk (count, modes byte = Predefined x 3, backward bitstream in ZSTD_encodeSequences order).
+// The only serial part is the three FSE state chains (literal length, match length, offset codes, each walked from the
+// last sequence to the first); what a state emits at a step does not depend on the other two.  So:
+//   hdr_seq_chains   a LANE per chain, 16 chunks per wave: per sequence the bits each chain emits (hst: value | nbits)
+//   hdr_seq_pack     a wave per chunk: every lane assembles the bits of one sequence (state bits + extra bits), a wave scan
+//                    places them, LDS atomics merge them
 // ---------------------------------------------------------------------------------------------
-struct HdrBits { uint8_t *p; unsigned long long acc; uint32_t nb, n; };
-__device__ __forceinline__ void hb_add(HdrBits &b, uint32_t v, uint32_t n)
-{
-    b.acc |= (unsigned long long)v << b.nb;
-    b.nb += n;
-    if (b.nb >= 32) {
-        if (b.n + 4 <= HDR_SEQ_CAP) store_u32_unaligned(b.p + b.n, (uint32_t)b.acc);
-        b.n += 4;
-        b.acc >>= 32;
-        b.nb -= 32;
-    }
-}
+struct HdrChainLds {
+    uint16_t state[3][64];
+    int32_t dnb[3][56], dfs[3][56];
+    uint8_t ll_code[64], ml_code[128];
+};
 __device__ __forceinline__ uint32_t hdr_ofv(const uint2 cur, const uint2 prev, bool has_prev)
 {
     // Offset_Value: 1 = "the offset of the previous sequence" (when this sequence has literals), else offset + 3; the first
     // sequence of a block is always explicit: no block depends on the offset history its predecessors leave behind
     return (has_prev && cur.y == prev.y && (cur.x & 0xFFFFu) > 0) ? 1u : cur.y + 3u;
 }
-__device__ __forceinline__ uint32_t hdr_fse_init(const HdrCt &ct, uint32_t sy)
+__device__ __forceinline__ void hdr_chain_tables(HdrChainLds &T)
 {
-    const uint32_t nb = (uint32_t)(ct.dnb[sy] + (1 << 15)) >> 16;
-    const uint32_t value = (nb << 16) - (uint32_t)ct.dnb[sy];
-    return ct.state[(value >> nb) + (uint32_t)ct.dfs[sy]];
-}
-__device__ __forceinline__ uint32_t hdr_fse_enc(const HdrCt &ct, HdrBits &bw, uint32_t st, uint32_t sy)
-{
-    const uint32_t nb = (st + (uint32_t)ct.dnb[sy]) >> 16;
-    hb_add(bw, st & ((1u << nb) - 1), nb);
-    return ct.state[(st >> nb) + (uint32_t)ct.dfs[sy]];
+    const uint32_t lane = threadIdx.x;
+    const HdrCt *ct[3] = {&c_hdr_ll, &c_hdr_ml, &c_hdr_of};
+    for (int c = 0; c < 3; c++) {
+        T.state[c][lane] = ct[c]->state[lane];
+        if (lane < 53) { T.dnb[c][lane] = ct[c]->dnb[lane]; T.dfs[c][lane] = ct[c]->dfs[lane]; }
+    }
+    T.ll_code[lane] = c_hll_code[lane];
+    T.ml_code[lane] = c_hml_code[lane];
+    T.ml_code[64 + lane] = c_hml_code[64 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 }
 
-__device__ void hdr_encode_sequences(const uint2 *__restrict__ hseq, uint32_t nseq, uint8_t *__restrict__ dst, HdrSide *side)
+// lane = 4 * (chunk of the wave) + chain (0 literal lengths, 1 match lengths, 2 offsets; 3 idles).
+// hst[i] = ll bits | ml bits << 9 | of bits << 18, each value | nbits << 6; side->pad = the three final states
+__device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, uint32_t nseq, uint32_t *__restrict__ hst, HdrSide *side, uint32_t c, bool on)
 {
-    HdrBits bw;
-    bw.p = dst; bw.acc = 0; bw.nb = 0; bw.n = 0;
-    // Number_of_Sequences (1 or 2 bytes: nseq < 0x7F00) and the modes byte
-    if (nseq < 128) hb_add(bw, nseq, 8);
-    else { hb_add(bw, (nseq >> 8) + 128, 8); hb_add(bw, nseq & 255, 8); }
-    hb_add(bw, 0, 8);
-    uint32_t st_ll = 0, st_of = 0, st_ml = 0;
+    uint32_t st = 0;
     bool first = true;
-    for (int hi = (int)nseq - 1; hi >= 0; hi -= 8) { // sequences hi, hi-1, ... hi-7 and the one in front of them (for the repeat-offset test)
-        const int lo = hi - 7 > 0 ? hi - 7 : 0;
+    for (int hi = on ? (int)nseq - 1 : -1; hi >= 0; hi -= 8) {
         uint2 buf[9];
 #pragma unroll
         for (int j = 0; j < 9; j++) { const int idx = hi - j; buf[j] = idx >= 0 ? hseq[idx] : make_uint2(0, 0); }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int idx = hi - j;
-            if (idx < lo) break;
-            const uint2 cur = buf[j];
-            const uint32_t ll = cur.x & 0xFFFFu, ml = cur.x >> 16;
-            const uint32_t ofv = hdr_ofv(cur, buf[j + 1], idx > 0);
-            const uint32_t lc = ll < 64 ? c_hll_code[ll] : (uint32_t)highbit32_d(ll) + 19;
-            const uint32_t mlb = ml - 3, mc = mlb < 128 ? c_hml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36;
-            const uint32_t oc = (uint32_t)highbit32_d(ofv);
-            if (first) {
-                st_ml = hdr_fse_init(c_hdr_ml, mc); st_of = hdr_fse_init(c_hdr_of, oc); st_ll = hdr_fse_init(c_hdr_ll, lc);
+            if (idx >= 0) {
+                const uint2 cur = buf[j];
+                uint32_t code;
+                if (c == 0) { const uint32_t ll = cur.x & 0xFFFFu; code = ll < 64 ? T.ll_code[ll] : (uint32_t)highbit32_d(ll) + 19; }
+                else if (c == 1) { const uint32_t mlb = (cur.x >> 16) - 3; code = mlb < 128 ? T.ml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36; }
+                else code = (uint32_t)highbit32_d(hdr_ofv(cur, buf[j + 1], idx > 0));
+                uint32_t outv = 0;
+                if (c < 3) {
+                    const int32_t dnb = T.dnb[c][code], dfs = T.dfs[c][code];
+                    if (first) { // FSE_initCState2: no output
+                        const uint32_t nb = (uint32_t)(dnb + (1 << 15)) >> 16;
+                        st = T.state[c][(((nb << 16) - (uint32_t)dnb) >> nb) + (uint32_t)dfs];
+                    } else {     // FSE_encodeSymbol
+                        const uint32_t nb = (st + (uint32_t)dnb) >> 16;
+                        outv = (st & ((1u << nb) - 1)) | (nb << 6);
+                        st = T.state[c][(st >> nb) + (uint32_t)dfs];
+                    }
+                }
                 first = false;
-            } else {
-                st_of = hdr_fse_enc(c_hdr_of, bw, st_of, oc);
-                st_ml = hdr_fse_enc(c_hdr_ml, bw, st_ml, mc);
-                st_ll = hdr_fse_enc(c_hdr_ll, bw, st_ll, lc);
-            }
-            hb_add(bw, ll - c_hll_base[lc], c_hll_bits[lc]);
-            hb_add(bw, ml - c_hml_base[mc], c_hml_bits[mc]);
-            hb_add(bw, ofv - (1u << oc), oc);
+                outv <<= 9 * c;
+                outv |= __shfl_down(outv, 1, WAVE) | __shfl_down(outv, 2, WAVE); // (lane c == 0 of the group: all three)
+                if (c == 0) hst[idx] = outv;
+            } else { (void)__shfl_down(0u, 1, WAVE); (void)__shfl_down(0u, 2, WAVE); }
         }
     }
-    hb_add(bw, st_ml & 63, 6); // FSE_flushCState: match lengths, offsets, literal lengths
-    hb_add(bw, st_of & 31, 5);
-    hb_add(bw, st_ll & 63, 6);
-    hb_add(bw, 1, 1);          // end mark
-    // the bits that have not made a whole dword yet
-    uint32_t tail_bytes = (bw.nb + 7) >> 3;
-    for (uint32_t j = 0; j < tail_bytes; j++) { if (bw.n + j < HDR_SEQ_CAP) dst[bw.n + j] = (uint8_t)(bw.acc >> (8 * j)); }
-    bw.n += tail_bytes;
-    side->sec_len = bw.n >= FQZ_CHUNK ? HDR_OVERFLOW : bw.n; // a section that long cannot beat the Raw block
+    uint32_t fin = st << (8 * c);
+    fin |= __shfl_down(fin, 1, WAVE) | __shfl_down(fin, 2, WAVE);
+    if (on && c == 0) side->pad = fin;
+}
+
+#define HDR_STAGE_WORDS ((HDR_SEQ_CAP + 16) / 4)
+struct HdrPackLds { uint32_t w[HDR_STAGE_WORDS]; uint8_t ll_code[64], ml_code[128]; };
+__device__ __forceinline__ void hdr_or_bits(uint32_t *w, uint32_t bitpos, unsigned long long v, uint32_t n)
+{
+    if (!n) return;
+    const uint32_t i = bitpos >> 5, sh = bitpos & 31;
+    if (i + 3 > HDR_STAGE_WORDS) return; // a section that long is discarded anyway (HDR_OVERFLOW)
+    atomicOr(&w[i], (uint32_t)(v << sh));
+    const unsigned long long hi = sh ? v >> (32 - sh) : v >> 16 >> 16;
+    if (sh + n > 32) atomicOr(&w[i + 1], (uint32_t)hi);
+    if (sh + n > 64) atomicOr(&w[i + 2], (uint32_t)(hi >> 32));
+}
+// one wave per chunk
+__device__ void hdr_seq_pack(HdrPackLds &S, const uint2 *__restrict__ hseq, uint32_t nseq, const uint32_t *__restrict__ hst, uint8_t *__restrict__ dst, HdrSide *side)
+{
+    const uint32_t lane = threadIdx.x;
+    S.ll_code[lane] = c_hll_code[lane];
+    S.ml_code[lane] = c_hml_code[lane];
+    S.ml_code[64 + lane] = c_hml_code[64 + lane];
+    const uint32_t est_words = (nseq * 9u + 64u) / 4u < HDR_STAGE_WORDS ? (nseq * 9u + 64u) / 4u : HDR_STAGE_WORDS; // <= 66 bits a sequence
+    for (uint32_t i = lane; i < est_words; i += 64) S.w[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // Number_of_Sequences (1 or 2 bytes: nseq < 0x7F00) and the modes byte
+    const uint32_t hb = nseq < 128 ? 2u : 3u;
+    if (lane == 0) S.w[0] = nseq < 128 ? nseq : (((nseq >> 8) + 128) | ((nseq & 255) << 8));
+    uint32_t P = 8 * hb;
+    for (int top = (int)nseq - 1; top >= 0; top -= 64) {
+        const int i = top - (int)lane;
+        uint32_t n1 = 0, n2 = 0;
+        unsigned long long v1 = 0, v2 = 0;
+        if (i >= 0) {
+            const uint2 cur = hseq[i];
+            const uint2 prev = i > 0 ? hseq[i - 1] : make_uint2(0, 0);
+            const uint32_t ll = cur.x & 0xFFFFu, ml = cur.x >> 16, ofv = hdr_ofv(cur, prev, i > 0);
+            const uint32_t lc = ll < 64 ? S.ll_code[ll] : (uint32_t)highbit32_d(ll) + 19;
+            const uint32_t mlb = ml - 3, mc = mlb < 128 ? S.ml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36;
+            const uint32_t oc = (uint32_t)highbit32_d(ofv);
+            if ((uint32_t)i + 1 < nseq) { // state bits: offsets, match lengths, literal lengths
+                const uint32_t h = hst[i];
+                const uint32_t bl = h & 63, nl = (h >> 6) & 7, bm = (h >> 9) & 63, nm = (h >> 15) & 7, bo = (h >> 18) & 63, no = (h >> 24) & 7;
+                v1 = (unsigned long long)bo | ((unsigned long long)bm << no) | ((unsigned long long)bl << (no + nm));
+                n1 = no + nm + nl;
+            }
+            const uint32_t lb = c_hll_bits[lc], mb = c_hml_bits[mc]; // extra bits: literal length, match length, offset
+            v2 = (unsigned long long)(ll - c_hll_base[lc]) | ((unsigned long long)(ml - c_hml_base[mc]) << lb) | ((unsigned long long)(ofv - (1u << oc)) << (lb + mb));
+            n2 = lb + mb + oc;
+        }
+        const uint32_t incl = wave_incl_scan(n1 + n2);
+        const uint32_t at = P + incl - (n1 + n2);
+        hdr_or_bits(S.w, at, v1, n1);
+        hdr_or_bits(S.w, at + n1, v2, n2);
+        P += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) { // FSE_flushCState: match lengths, offsets, literal lengths; then the end mark
+        const uint32_t fin = side->pad;
+        const unsigned long long tail = (unsigned long long)((fin >> 8) & 63) | ((unsigned long long)((fin >> 16) & 31) << 6) | ((unsigned long long)(fin & 63) << 11) | (1ull << 17);
+        hdr_or_bits(S.w, P, tail, 18);
+    }
+    P += 18;
+    const uint32_t bytes = (P + 7) >> 3;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (bytes >= FQZ_CHUNK) { if (lane == 0) side->sec_len = HDR_OVERFLOW; return; } // a section that long cannot beat the Raw block
+    for (uint32_t i = lane; i < (bytes + 3) / 4; i += 64) ((uint32_t *)dst)[i] = S.w[i];
+    if (lane == 0) side->sec_len = bytes;
 }
