@@ -1856,6 +1856,8 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             HIP_TRY(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
         }
+        static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: one stream (standalone kernel times)
+        const hipStream_t sd = dbg_serial ? st : d.side;
         HIP_TRY(hipEventRecord(d.ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(d.side, d.ev_fork, 0));
         PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, st, d_in, info, dch, darena, dbg, early));
@@ -1864,11 +1866,11 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             PROF(ctx, st, "k_dec_seq_fse", hipLaunchKernelGGL(k_dec_seq_fse, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_in, info, dch, darena));
             PROF(ctx, st, "k_dec_seq_exec", hipLaunchKernelGGL(k_dec_seq_exec, dim3(n_chunks), dim3(64), 0, st, info, dch, darena));
         }
-        PROF(ctx, d.side, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, d.side, d_in, info, dch, darena, dbg, late));
-        PROF(ctx, d.side, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, d.side, d_in, info, dch, darena, late));
+        PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late));
+        PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, sd, d_in, info, dch, darena, late));
         if (n_frames) { // content checksums of the decoded frames: beside the walks / on the side stream, like the decodes they check
             PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, st, d_in, info, dfr, n_frames, darena, early));
-            PROF(ctx, d.side, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, d.side, d_in, info, dfr, n_frames, darena, late));
+            PROF(ctx, sd, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, sd, d_in, info, dfr, n_frames, darena, late));
         }
         HIP_TRY(hipEventRecord(d.ev_join, d.side));
         forked = true;

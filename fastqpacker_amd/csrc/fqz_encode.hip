@@ -1314,15 +1314,17 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         HIP_TRY(hipEventCreateWithFlags(&e.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
     }
+    static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: everything on one stream (standalone kernel times)
+    const hipStream_t sd = dbg_serial ? st : e.side;
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side, e.ev_fork, 0));
     // the headers chain (model -> sequences -> entropy over the literals) runs beside the entropy coder of the other streams too
     const uint32_t hgroup_cap = hcap / FQZ_GROUP + e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + e.block_cap + 8 : group_cap;
-    PROF(ctx, e.side, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, e.side, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside));
-    PROF(ctx, e.side, "k_hdr_seq1", hipLaunchKernelGGL(k_hdr_seq1, dim3((hcap + 15) / 16), dim3(64), 0, e.side, info, hcap, hseq, hst, hside));
-    PROF(ctx, e.side, "k_hdr_seq2", hipLaunchKernelGGL(k_hdr_seq2, dim3(hcap), dim3(64), 0, e.side, info, hcap, hseq, hst, hsec, hside));
-    PROF(ctx, e.side, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, e.side, info, hmap, arena, slots, csize, hord, hcap, hlit, hsec, hside));
-    PROF(ctx, e.side, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, e.side, info, e.xmap.as<uint4>(), arena, npos, xsum));
+    PROF(ctx, sd, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, sd, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside));
+    PROF(ctx, sd, "k_hdr_seq1", hipLaunchKernelGGL(k_hdr_seq1, dim3((hcap + 15) / 16), dim3(64), 0, sd, info, hcap, hseq, hst, hside));
+    PROF(ctx, sd, "k_hdr_seq2", hipLaunchKernelGGL(k_hdr_seq2, dim3(hcap), dim3(64), 0, sd, info, hcap, hseq, hst, hsec, hside));
+    PROF(ctx, sd, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, sd, info, hmap, arena, slots, csize, hord, hcap, hlit, hsec, hside));
+    PROF(ctx, sd, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd, info, e.xmap.as<uint4>(), arena, npos, xsum));
     HIP_TRY(hipEventRecord(e.ev_join, e.side));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join, 0));

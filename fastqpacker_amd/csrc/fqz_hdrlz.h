@@ -84,6 +84,8 @@ __constant__ const uint8_t c_hml_code[128] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 
 // ---------------------------------------------------------------------------------------------
 // k_hdr_model: one workgroup per headers chunk -> its sequences (hseq: ll | ml << 16, offset) and its literals (hlit)
 // ---------------------------------------------------------------------------------------------
+#define HDR_RUN_MAX 64u  // literal runs up to this long are copied by their own lane
+#define HDR_STAGE 4096u  // literal bytes staged in LDS before they leave in 16-byte pieces
 #define HDR_TPAD 16u // bytes in front of the chunk in LDS: the backward compares read 8 bytes at a time
 struct HdrModelLds {
     uint8_t text[HDR_TPAD + FQZ_CHUNK + 16];
@@ -91,8 +93,9 @@ struct HdrModelLds {
     uint16_t hs[HDR_MAX_SEQ / 2 + 2], hl[HDR_MAX_SEQ / 2 + 2], tl[HDR_MAX_SEQ / 2 + 2]; // head start / length, tail length
     uint32_t sh[8];
     uint32_t carry[2];      // sequences << 16 | matched bytes; end of the last match so far
-    uint32_t q_n;           // long literal runs waiting for a cooperative copy
-    uint32_t q[64][3];      // {source (chunk-relative), destination (literal offset), bytes}
+    uint32_t q_n;           // long literal runs (> HDR_RUN_MAX bytes) of the strip: all threads copy them
+    uint32_t q[FQZ_CHUNK / HDR_RUN_MAX + 4][3]; // {source (chunk-relative), destination (literal offset), bytes}; a chunk cannot hold more
+    __attribute__((aligned(16))) uint8_t stage[HDR_STAGE + 16];
 };
 __device__ __forceinline__ unsigned long long hdr_ld64(const uint8_t *p) { unsigned long long v; __builtin_memcpy(&v, p, 8); return v; }
 
@@ -191,7 +194,10 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
         S.hs[k] = (uint16_t)h_start; S.hl[k] = (uint16_t)h_len; S.tl[k] = (uint16_t)tail;
     }
     __syncthreads();
-    // ---- candidates in stream order: A_k = tail of record k-1 (+ the head of record k when they touch), B_k = head of record k alone
+    // ---- candidates in stream order: A_k = tail of record k-1 (+ the head of record k when they touch), B_k = head of record k alone.
+    //      The literals (the bytes between the matches) are compacted through a staging window in LDS and leave in whole
+    //      16-byte pieces: a store per literal byte and lane is what the vector memory pipeline is slowest at
+    uint32_t a0 = 0; // literal offset of stage[0] (a multiple of 16); stage[0 .. lit_end - a0) is filled and not yet flushed
     for (uint32_t k0 = 1; k0 <= n_in; k0 += 256) {
         const uint32_t k = k0 + t;
         uint32_t posA = 0, lenA = 0, posB = 0, lenB = 0, off = 0;
@@ -209,34 +215,58 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
         const uint32_t my_end = lenB ? posB + lenB : (lenA ? posA + lenA : 0u);
         uint32_t ex, ex_e, tot, tot_e;
         hdr_scan2((cnt << 16) | (lenA + lenB), my_end, S.sh, &ex, &ex_e, &tot, &tot_e);
-        ex += S.carry[0];
-        ex_e = ex_e > S.carry[1] ? ex_e : S.carry[1];
+        const uint32_t c0v = S.carry[0], c1v = S.carry[1];
+        ex += c0v;
+        ex_e = ex_e > c1v ? ex_e : c1v;
         const uint32_t ex_c = ex >> 16, ex_m = ex & 0xFFFFu;
-        auto emit = [&](uint32_t idx, uint32_t prev_end, uint32_t matched_before, uint32_t pos, uint32_t ml) {
-            const uint32_t ll = pos - prev_end, lit_off = prev_end - matched_before;
-            hseq[idx] = make_uint2(ll | (ml << 16), off);
-            if (ll <= 32) { for (uint32_t j = 0; j < ll; j++) hlit[lit_off + j] = text[prev_end + j]; }
-            else {
-                const uint32_t qi = atomicAdd(&S.q_n, 1u);
-                if (qi < 64) { S.q[qi][0] = prev_end; S.q[qi][1] = lit_off; S.q[qi][2] = ll; }
-                else for (uint32_t j = 0; j < ll; j++) hlit[lit_off + j] = text[prev_end + j];
-            }
-        };
-        if (lenA) emit(ex_c, ex_e, ex_m, posA, lenA);
-        if (lenB) emit(ex_c + (lenA ? 1u : 0u), lenA ? posA + lenA : ex_e, ex_m + lenA, posB, lenB);
+        // this thread's literal runs: text[src, src + ll) -> literal offset dst
+        uint32_t srcA = 0, dstA = 0, llA = 0, srcB = 0, dstB = 0, llB = 0;
+        if (lenA) { srcA = ex_e; llA = posA - ex_e; dstA = ex_e - ex_m; hseq[ex_c] = make_uint2(llA | (lenA << 16), off); }
+        if (lenB) {
+            srcB = lenA ? posA + lenA : ex_e; llB = posB - srcB; dstB = srcB - (ex_m + lenA);
+            hseq[ex_c + (lenA ? 1u : 0u)] = make_uint2(llB | (lenB << 16), off);
+        }
+        if (llA > HDR_RUN_MAX) { const uint32_t qi = atomicAdd(&S.q_n, 1u); S.q[qi][0] = srcA; S.q[qi][1] = dstA; S.q[qi][2] = llA; llA = 0; }
+        if (llB > HDR_RUN_MAX) { const uint32_t qi = atomicAdd(&S.q_n, 1u); S.q[qi][0] = srcB; S.q[qi][1] = dstB; S.q[qi][2] = llB; llB = 0; }
+        const uint32_t new_end = tot_e > c1v ? tot_e : c1v;
+        const uint32_t lit_end = new_end - ((c0v + tot) & 0xFFFFu); // literals in front of the last match so far
         __syncthreads();
-        if (t == 0) { S.carry[0] += tot; S.carry[1] = tot_e > S.carry[1] ? tot_e : S.carry[1]; }
-        // long literal runs of this strip: all threads copy
-        const uint32_t qn = S.q_n < 64 ? S.q_n : 64;
-        for (uint32_t qi = 0; qi < qn; qi++)
-            for (uint32_t j = t; j < S.q[qi][2]; j += 256) hlit[S.q[qi][1] + j] = text[S.q[qi][0] + j];
+        if (t == 0) { S.carry[0] = c0v + tot; S.carry[1] = new_end; }
+        const uint32_t qn = S.q_n;
+        for (;;) { // windows of HDR_STAGE literal bytes (one, unless the strip holds long runs)
+            const uint32_t w_end = a0 + HDR_STAGE;
+            auto put = [&](uint32_t src, uint32_t dst, uint32_t ll) {
+                const uint32_t a = dst > a0 ? dst : a0, b = dst + ll < w_end ? dst + ll : w_end;
+                for (uint32_t j = a; j < b; j++) S.stage[j - a0] = text[src + (j - dst)];
+            };
+            if (llA) put(srcA, dstA, llA);
+            if (llB) put(srcB, dstB, llB);
+            for (uint32_t qi = 0; qi < qn; qi++) { // long runs: all threads copy
+                const uint32_t src = S.q[qi][0], dst = S.q[qi][1], ll = S.q[qi][2];
+                const uint32_t a = dst > a0 ? dst : a0, b = dst + ll < w_end ? dst + ll : w_end;
+                for (uint32_t j = a + t; j < b; j += 256) S.stage[j - a0] = text[src + (j - dst)];
+            }
+            __syncthreads();
+            const uint32_t have_end = lit_end < w_end ? lit_end : w_end, flush_end = have_end & ~15u;
+            for (uint32_t j = a0 + t * 16; j < flush_end; j += 256 * 16) *(uint4 *)(hlit + j) = *(const uint4 *)&S.stage[j - a0];
+            uint32_t rem = 0;
+            if (t < have_end - flush_end) rem = S.stage[flush_end - a0 + t]; // (< 16 bytes wait for the next pieces)
+            __syncthreads();
+            if (t < have_end - flush_end) S.stage[t] = (uint8_t)rem;
+            a0 = flush_end;
+            if (lit_end <= w_end) break;
+        }
         __syncthreads();
         if (t == 0) S.q_n = 0;
     }
     __syncthreads();
-    // ---- the literals behind the last match
+    // ---- what is left in the stage, then the literals behind the last match
     const uint32_t nseq = S.carry[0] >> 16, matched = S.carry[0] & 0xFFFFu, last_end = S.carry[1];
-    if (nseq) for (uint32_t j = last_end + t; j < mk; j += 256) hlit[j - matched] = text[j];
+    if (nseq) {
+        const uint32_t lit_end = last_end - matched;
+        if (t < lit_end - a0) hlit[a0 + t] = S.stage[t];
+        for (uint32_t j = last_end + t; j < mk; j += 256) hlit[j - matched] = text[j];
+    }
     if (t == 0) { side->nseq = nseq; side->n_lit = mk - matched; side->sec_len = 0; side->pad = 0; }
 }
 
