@@ -1863,7 +1863,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, st, d_in, info, dch, darena, dbg, early));
         PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, st, d_in, info, dch, darena, early));
         if (any_seq) { // headers blocks with sequences: their literals are in the scratch now
-            PROF(ctx, st, "k_dec_seq_fse", hipLaunchKernelGGL(k_dec_seq_fse, dim3((n_chunks + 63) / 64), dim3(64), 0, st, d_in, info, dch, darena));
+            PROF(ctx, st, "k_dec_seq_fse", hipLaunchKernelGGL(k_dec_seq_fse, dim3((n_chunks + 15) / 16), dim3(64), 0, st, d_in, info, dch, darena));
             PROF(ctx, st, "k_dec_seq_exec", hipLaunchKernelGGL(k_dec_seq_exec, dim3(n_chunks), dim3(64), 0, st, info, dch, darena));
         }
         PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late));

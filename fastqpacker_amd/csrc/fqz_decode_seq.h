@@ -57,155 +57,132 @@ constexpr SeqDt seq_make_all()
 }
 __constant__ const SeqDt c_seq_dt = seq_make_all();
 
-// Per decoding state, packed for one 64-bit LDS read: x = symbol | nbits << 8 | next-state base << 16 (c_seq_dt),
-// y = base of the value the symbol stands for | its extra bits << 24 (offsets: y = extra bits, the value is 1 << bits + extra)
-#define SEQ_WIN 128u          // bytes of a lane's bit stream staged in LDS at a time
-#define SEQ_WIN_STRIDE 33u    // dwords between the windows of neighbouring lanes (odd: no systematic bank conflicts)
+// k_dec_seq_fse: FOUR lanes per block (16 blocks per wave): lane 0 follows the literal-length state, lane 1 the match-length
+// state, lane 2 the offset state (lane 3 idles), all with the same instructions: a step is one table read (per decoding
+// state, packed for one 64-bit LDS read: x = symbol | nbits << 8 | next-state base << 16 (c_seq_dt), y = base of the value the
+// symbol stands for | its extra bits << 24), an exchange of the six bit counts inside the quad (DPP), and two bit-field reads
+// from the block's stream window in LDS.  The bit position is the only thing the three chains share.
+#define SEQ_WIN 128u          // bytes of a block's bit stream staged in LDS at a time (a multiple of 16)
+#define SEQ_WIN_STRIDE 33u    // dwords between the windows of neighbouring blocks
 struct SeqFseLds {
-    uint2 ll[64], ml[64], of[32];
-    uint32_t win[64 * SEQ_WIN_STRIDE + 4];
+    uint2 tab[3][64];
+    uint32_t win[16 * SEQ_WIN_STRIDE + 4];
 };
-
-// backward bit reader over a lane's window: the stream bytes [wbase, wbase + SEQ_WIN) sit in LDS; bytes are consumed from
-// the end of the stream towards its start, four at a time
-struct SeqBits {
-    unsigned long long buf; // next bits at the MSB end
-    int avail;              // valid bits in buf
-    int byte_pos;           // stream bytes [0, byte_pos) not merged yet
-    int wbase;              // stream offset of the window's first byte
-};
-__device__ __forceinline__ void seq_window_load(uint32_t *win, const uint8_t *p, int byte_pos, int *wbase)
+template <int K>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) // the value of lane K of this lane's quad
 {
-    int wb = byte_pos - (int)SEQ_WIN;
-    wb = wb < 0 ? 0 : wb;
-    *wbase = wb;
-    // (a piece may read up to 15 bytes behind byte_pos: the rest of the stream, or - behind the section - the frame's checksum
-    //  and the payloads that follow the headers payload in every block)
-#pragma unroll
-    for (uint32_t q = 0; q < SEQ_WIN / 16; q++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (wb + (int)(16 * q) < byte_pos) v = load_u128_unaligned(p + wb + 16 * q);
-        win[4 * q] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
-    }
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
 }
-__device__ __forceinline__ void seq_refill(SeqBits &b, const uint32_t *win)
+// bits [lo, lo + n) of the stream (n <= 24) from the window that starts at stream byte wb (a multiple of 4)
+__device__ __forceinline__ uint32_t seq_bits(const uint32_t *win, int wb, int lo, uint32_t n)
 {
-    if (b.avail <= 32 && b.byte_pos > 0) {
-        const int take = b.byte_pos < 4 ? b.byte_pos : 4;
-        const int at = b.byte_pos - 4 - b.wbase;                 // window offset of the dword that ends at byte_pos (>= -3)
-        const int a4 = at >> 2;                                   // (arithmetic shift: -1 for at < 0)
-        const uint32_t lo = a4 >= 0 ? win[a4] : 0u, hi = win[a4 + 1];
-        const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)at & 3u);
-        const uint32_t keep = take == 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (8 * take)); // a partial first word: its low bytes precede the stream
-        b.buf |= (unsigned long long)(w & keep) << (32 - b.avail);
-        b.avail += 8 * take;
-        b.byte_pos -= take;
-    }
-}
-__device__ __forceinline__ uint32_t seq_take(SeqBits &b, uint32_t nb)
-{
-    const uint32_t v = nb ? (uint32_t)(b.buf >> (64 - nb)) : 0u;
-    b.buf = nb ? b.buf << nb : b.buf;
-    b.avail -= (int)nb;
-    return v;
+    const uint32_t rel = (uint32_t)(lo - 8 * wb), d = rel >> 5;
+    const uint32_t v = __builtin_amdgcn_alignbit(win[d + 1], win[d], rel & 31u);
+    return n ? v & (0xFFFFFFFFu >> (32 - n)) : 0u;
 }
 
 __global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena)
 {
     __shared__ SeqFseLds T;
-    const uint32_t lane = threadIdx.x, id = blockIdx.x * 64 + lane;
+    const uint32_t lane = threadIdx.x, g = lane >> 2, c = lane & 3, id = blockIdx.x * 16 + g;
     if (info->status) return;
-    DecChunk c;
-    c.seq_len = 0;
-    if (id < info->n_chunks) c = chunks[id];
-    if (!__ballot(c.seq_len != 0)) return;
+    DecChunk ch;
+    ch.seq_len = 0;
+    if (id < info->n_chunks) ch = chunks[id];
+    if (!__ballot(ch.seq_len != 0)) return;
     {
         const uint32_t el = c_seq_dt.ll[lane], em = c_seq_dt.ml[lane];
-        T.ll[lane] = make_uint2(el, c_ll_base[el & 0xFF] | ((uint32_t)c_ll_bits[el & 0xFF] << 24));
-        T.ml[lane] = make_uint2(em, c_ml_base[em & 0xFF] | ((uint32_t)c_ml_bits[em & 0xFF] << 24));
-        if (lane < 32) { const uint32_t eo = c_seq_dt.of[lane]; T.of[lane] = make_uint2(eo, eo & 0xFF); }
+        T.tab[0][lane] = make_uint2(el, c_ll_base[el & 0xFF] | ((uint32_t)c_ll_bits[el & 0xFF] << 24));
+        T.tab[1][lane] = make_uint2(em, c_ml_base[em & 0xFF] | ((uint32_t)c_ml_bits[em & 0xFF] << 24));
+        const uint32_t eo = c_seq_dt.of[lane & 31];
+        T.tab[2][lane] = make_uint2(eo, (eo & 0xFF) << 24); // offsets: the code is the number of extra bits, the base 1 << code
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    const bool on = c.seq_len != 0;
-    uint8_t *scr = arena + (on ? c.dst_off : 0u);
+    if (!ch.seq_len) return; // (whole quads leave)
+    uint8_t *scr = arena + ch.dst_off;
     uint2 *out = (uint2 *)(scr + FQZ_CHUNK);
-    const uint8_t *sq = in + (on ? c.src_off + c.csize - c.seq_len : 0u);
-    const uint32_t sn = c.seq_len;
+    const uint8_t *sq = in + ch.src_off + ch.csize - ch.seq_len;
+    const uint32_t sn = ch.seq_len;
     int verdict = 0; // 0 fine, 1 = not our profile (general path), 2 = corrupt
-    uint32_t nseq = 0, shdr = 1;
-    if (on) {
-        nseq = sq[0];
-        if (nseq >= 128) {
-            if (nseq == 255 || sn < 2) verdict = 1;
-            else { nseq = ((nseq - 128) << 8) + sq[1]; shdr = 2; }
+    uint32_t nseq = sq[0], shdr = 1;
+    if (nseq >= 128) {
+        if (nseq == 255 || sn < 2) verdict = 1;
+        else { nseq = ((nseq - 128) << 8) + sq[1]; shdr = 2; }
+    }
+    if (!verdict && (nseq == 0 || nseq > DSEQ_MAX || sn < shdr + 2 || sq[shdr] != 0)) verdict = 1;
+    if (!verdict && sq[sn - 1] == 0) verdict = 2; // no end mark
+    const uint8_t *bp = sq + shdr + 1;             // the bit stream: bn bytes, read from its last bit down
+    const int bn = verdict ? 0 : (int)(sn - shdr - 1);
+    uint32_t *win = T.win + g * SEQ_WIN_STRIDE;
+    int p = 0, wb = 0;                              // bits [0, p) are still to be read; the window holds the bytes [wb, wb + SEQ_WIN)
+    auto window = [&]() {
+        int top = (p + 7) >> 3;
+        wb = top > (int)SEQ_WIN ? (top - (int)SEQ_WIN + 3) & ~3 : 0;
+        // (a piece may read up to 15 bytes behind the stream: the frame's checksum and the payloads that follow the headers payload)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) {
+            const uint32_t piece = c + 4 * q;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (wb + (int)(16 * piece) < bn) v = load_u128_unaligned(bp + wb + 16 * piece);
+            win[4 * piece] = v.x; win[4 * piece + 1] = v.y; win[4 * piece + 2] = v.z; win[4 * piece + 3] = v.w;
         }
-        if (!verdict && (nseq == 0 || nseq > DSEQ_MAX || sn < shdr + 2 || sq[shdr] != 0)) verdict = 1;
-        if (!verdict && sq[sn - 1] == 0) verdict = 2; // no end mark
+        if (c == 0) win[32] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (read by the other lanes of the quad: LDS operations of a wave execute in order)
+        __builtin_amdgcn_wave_barrier();
+    };
+    uint32_t st = 0;
+    if (!verdict) {
+        p = bn * 8 - (8 - highbit32_d(bp[bn - 1])); // without the end mark and the zero bits above it
+        if (p < 17) verdict = 2;
     }
-    if (!on || verdict) nseq = 0;
-    const uint8_t *bp = sq + shdr + 1;            // the bit stream
-    const int bn = on && !verdict ? (int)(sn - shdr - 1) : 0;
-    uint32_t *win = T.win + lane * SEQ_WIN_STRIDE;
-    SeqBits br;
-    br.buf = 0; br.avail = 0; br.byte_pos = bn; br.wbase = 0;
-    int bits_left = 0;
-    if (nseq) {
-        seq_window_load(win, bp, br.byte_pos, &br.wbase);
-        seq_refill(br, win);
-        seq_refill(br, win);
-        const int pad = 8 - highbit32_d(bp[bn - 1]); // end mark and the zero bits above it
-        br.buf <<= pad;
-        br.avail -= pad;
-        bits_left = bn * 8 - pad;
-    }
-    uint32_t st_ll = 0, st_of = 0, st_ml = 0;
-    if (nseq) {
-        seq_refill(br, win);
-        st_ll = seq_take(br, 6); st_of = seq_take(br, 5); st_ml = seq_take(br, 6);
-        bits_left -= 17;
+    if (!verdict) {
+        window();
+        // initial states: literal lengths (6 bits), offsets (5), match lengths (6)
+        st = seq_bits(win, wb, c == 0 ? p - 6 : (c == 2 ? p - 11 : p - 17), c == 2 ? 5u : 6u);
+        p -= 17;
     }
     uint32_t o = 0, lit_used = 0, prev_off = 0;
-    for (uint32_t i = 0; i < nseq; i++) {
-        if (br.byte_pos - br.wbase < 12 && br.wbase > 0) seq_window_load(win, bp, br.byte_pos, &br.wbase); // (three refills may follow before the next check)
-        const uint2 e_ll = T.ll[st_ll & 63], e_of = T.of[st_of & 31], e_ml = T.ml[st_ml & 63];
-        const uint32_t oc = e_of.y;
-        if (oc > 24) { verdict = 1; break; }
-        seq_refill(br, win);
-        const uint32_t of_val = (1u << oc) + seq_take(br, oc);
-        seq_refill(br, win);
-        const uint32_t mb = e_ml.y >> 24, lb = e_ll.y >> 24;
-        const uint32_t ml = (e_ml.y & 0xFFFFFFu) + seq_take(br, mb);
-        const uint32_t ll = (e_ll.y & 0xFFFFFFu) + seq_take(br, lb);
-        bits_left -= (int)(oc + mb + lb);
-        if (i + 1 < nseq) {
-            seq_refill(br, win);
-            const uint32_t nl = (e_ll.x >> 8) & 0xFF, nm = (e_ml.x >> 8) & 0xFF, no = (e_of.x >> 8) & 0xFF;
-            st_ll = (e_ll.x >> 16) + seq_take(br, nl);
-            st_ml = (e_ml.x >> 16) + seq_take(br, nm);
-            st_of = (e_of.x >> 16) + seq_take(br, no);
-            bits_left -= (int)(nl + nm + no);
-        }
-        if (bits_left < 0) { verdict = 2; break; }
+    for (uint32_t i = 0; i < nseq && !verdict; i++) {
+        if (p - 80 < 8 * wb && wb > 0) window();
+        const uint2 e = T.tab[c == 3 ? 0 : c][st & 63];
+        const bool last = i + 1 == nseq;
+        const uint32_t xb = c == 3 ? 0u : e.y >> 24, sb = (last || c == 3) ? 0u : (e.x >> 8) & 0xFF;
+        const uint32_t x0 = quad_bcast<0>(xb), x1 = quad_bcast<1>(xb), x2 = quad_bcast<2>(xb);
+        const uint32_t s0 = quad_bcast<0>(sb), s1 = quad_bcast<1>(sb);
+        const uint32_t s2 = quad_bcast<2>(sb);
+        const uint32_t total = x0 + x1 + x2 + s0 + s1 + s2;
+        if (x2 > 24) { verdict = 1; break; }
+        if ((int)total > p) { verdict = 2; break; }
+        // stream order (from the top): offset extra bits, match-length extra bits, literal-length extra bits, then the state
+        // bits of literal lengths, match lengths, offsets
+        const uint32_t startA = c == 2 ? 0u : (c == 1 ? x2 : x2 + x1);
+        const uint32_t startB = x0 + x1 + x2 + (c == 0 ? 0u : (c == 1 ? s0 : s0 + s1));
+        const uint32_t A = seq_bits(win, wb, p - (int)(startA + xb), xb), B = seq_bits(win, wb, p - (int)(startB + sb), sb);
+        const uint32_t val = (c == 2 ? 1u << xb : e.y & 0xFFFFFFu) + A;
+        if (!last) st = (e.x >> 16) + B;
+        p -= (int)total;
+        const uint32_t ll = quad_bcast<0>(val), ml = quad_bcast<1>(val), of_val = quad_bcast<2>(val);
         uint32_t offset;
         if (of_val > 3) offset = of_val - 3;
         else if (of_val == 1 && ll > 0 && i > 0) offset = prev_off; // "the offset of the previous sequence" (of this block)
         else { verdict = 1; break; }
         prev_off = offset;
-        if (ll > c.regen - lit_used || ll > c.out_len - o || ml > c.out_len - o - ll) { verdict = 2; break; }
+        if (ll > ch.regen - lit_used || ll > ch.out_len - o || ml > ch.out_len - o - ll) { verdict = 2; break; }
         if (offset > o + ll) { verdict = 1; break; } // reaches in front of the block: not ours
-        out[i] = make_uint2(ll | (ml << 16), offset);
+        if (c == 0) out[i] = make_uint2(ll | (ml << 16), offset);
         lit_used += ll;
         o += ll + ml;
     }
-    if (!on) return;
-    if (!verdict && (bits_left != 0 || o + (c.regen - lit_used) != c.out_len)) verdict = 2;
-    *(uint32_t *)(scr + 2 * FQZ_CHUNK) = verdict ? DSEQ_INVALID : nseq;
-    // (a corrupt block is left to the general path as well: it gives the authoritative verdict)
-    if (verdict) dec_fail(info, FQZ_DEC_RETRY_GENERAL);
+    if (!verdict && (p != 0 || o + (ch.regen - lit_used) != ch.out_len)) verdict = 2;
+    if (c == 0) {
+        *(uint32_t *)(scr + 2 * FQZ_CHUNK) = verdict ? DSEQ_INVALID : nseq;
+        // (a corrupt block is left to the general path as well: it gives the authoritative verdict)
+        if (verdict) dec_fail(info, FQZ_DEC_RETRY_GENERAL);
+    }
 }
 
-#define SEQ_LWIN 2048u // literal bytes of a batch of sequences staged at a time
+#define SEQ_LWIN 4096u // literal bytes staged at a time (several batches of sequences)
 struct SeqExecLds {
     uint8_t out[FQZ_CHUNK + 16];
     uint8_t lw[SEQ_LWIN + 32];
@@ -227,27 +204,32 @@ __global__ __launch_bounds__(64) void k_dec_seq_exec(DecInfo *info, const DecChu
     if (nseq == DSEQ_INVALID || nseq > DSEQ_MAX) return;
     const uint32_t n_lit = c.regen, n_out = c.out_len;
     uint32_t o = 0, lp = 0;
-    // literal bytes [from, from + n) of the block -> S.lw (n <= SEQ_LWIN); `from` is arbitrary, the loads are 16-byte pieces
-    auto stage = [&](uint32_t from, uint32_t n) {
-        const uint32_t a0 = from & ~15u;
+    // the literal window: S.lw[ws_sh + k] = literal ws + k for k < ws_n
+    uint32_t ws = 0, ws_n = 0, ws_sh = 0;
+    auto stage = [&](uint32_t from) { // literals [from, from + SEQ_LWIN) of the block (as far as they exist), 16-byte pieces
+        const uint32_t a0 = from & ~15u, n = n_lit - from < SEQ_LWIN ? n_lit - from : SEQ_LWIN;
+        SEQ_LDS_ORDER();
         for (uint32_t i = lane * 16; i < n + (from - a0); i += 64 * 16) *(uint4 *)&S.lw[i] = *(const uint4 *)(scr + a0 + i); // (the scratch is padded)
-        return from - a0; // S.lw[that + k] = literal from + k
+        SEQ_LDS_ORDER();
+        ws = from; ws_n = n; ws_sh = from - a0;
     };
+    uint2 q = make_uint2(0, 0);
+    if (lane < nseq) q = seqs[lane];
+    stage(0);
     for (uint32_t base = 0; base < nseq; base += 64) {
         const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
-        uint2 q = make_uint2(0, 0);
-        if (lane < cnt) q = seqs[base + lane];
+        uint2 qn = make_uint2(0, 0); // the next batch: in flight while this one runs
+        if (base + 64 + lane < nseq) qn = seqs[base + 64 + lane];
         const uint32_t ll = q.x & 0xFFFFu, ml = q.x >> 16;
         const uint32_t in_o = wave_incl_scan(ll + ml), in_l = wave_incl_scan(ll);
-        const uint32_t op = o + in_o - (ll + ml), lq = in_l - ll;   // literals go to out[op, op + ll); lq: offset in the batch's literals
+        const uint32_t op = o + in_o - (ll + ml), lq = lp + in_l - ll; // literals [lq, lq + ll) go to out[op, op + ll), the match behind them
         const uint32_t l_tot = (uint32_t)__builtin_amdgcn_readlane((int)in_l, 63);
-        for (uint32_t w0 = 0; w0 < l_tot; w0 += SEQ_LWIN) {          // the batch's literals, a window at a time
-            const uint32_t wn = l_tot - w0 < SEQ_LWIN ? l_tot - w0 : SEQ_LWIN;
-            SEQ_LDS_ORDER();
-            const uint32_t sh = stage(lp + w0, wn);
-            SEQ_LDS_ORDER();
-            const uint32_t a = lq > w0 ? lq : w0, b = lq + ll < w0 + wn ? lq + ll : w0 + wn; // this lane's part of the window
-            for (uint32_t k = a; k < b; k++) S.out[op + (k - lq)] = S.lw[sh + (k - w0)];
+        for (uint32_t w0 = lp; w0 < lp + l_tot;) { // the batch's literals through the window (one pass unless a run is very long)
+            if (w0 < ws || w0 >= ws + ws_n || (lp + l_tot > ws + ws_n && w0 == lp && ws + ws_n < n_lit)) stage(w0);
+            const uint32_t w1 = ws + ws_n < lp + l_tot ? ws + ws_n : lp + l_tot;
+            const uint32_t a = lq > w0 ? lq : w0, b = lq + ll < w1 ? lq + ll : w1; // this lane's part of [w0, w1)
+            for (uint32_t k = a; k < b; k++) S.out[op + (k - lq)] = S.lw[ws_sh + (k - ws)];
+            w0 = w1;
         }
         SEQ_LDS_ORDER();
         const uint32_t mdst = op + ll;
@@ -261,13 +243,13 @@ __global__ __launch_bounds__(64) void k_dec_seq_exec(DecInfo *info, const DecChu
         }
         o += (uint32_t)__builtin_amdgcn_readlane((int)in_o, 63);
         lp += l_tot;
+        q = qn;
     }
-    for (uint32_t w0 = lp; w0 < n_lit; w0 += SEQ_LWIN) { // the literals behind the last match
-        const uint32_t wn = n_lit - w0 < SEQ_LWIN ? n_lit - w0 : SEQ_LWIN;
-        SEQ_LDS_ORDER();
-        const uint32_t sh = stage(w0, wn);
-        SEQ_LDS_ORDER();
-        for (uint32_t k = lane; k < wn; k += 64) S.out[o + (w0 - lp) + k] = S.lw[sh + k];
+    for (uint32_t w0 = lp; w0 < n_lit;) { // the literals behind the last match
+        if (w0 < ws || w0 >= ws + ws_n) stage(w0);
+        const uint32_t w1 = ws + ws_n;
+        for (uint32_t k = w0 + lane; k < w1; k += 64) S.out[o + (k - lp)] = S.lw[ws_sh + (k - ws)];
+        w0 = w1;
     }
     SEQ_LDS_ORDER();
     uint8_t *dst = arena + c.out_off; // 16-byte aligned (a chunk of a 16-aligned stream)

@@ -278,6 +278,7 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
 //   hdr_seq_pack     a wave per chunk: every lane assembles the bits of one sequence (state bits + extra bits), a wave scan
 //                    places them, LDS atomics merge them
 // ---------------------------------------------------------------------------------------------
+#define HDR_CB 24u // sequences per trip of hdr_seq_chains
 struct HdrChainLds {
     uint16_t state[3][64];
     int32_t dnb[3][56], dfs[3][56];
@@ -310,12 +311,13 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
 {
     uint32_t st = 0;
     bool first = true;
-    for (int hi = on ? (int)nseq - 1 : -1; hi >= 0; hi -= 8) {
-        uint2 buf[9];
+    // HDR_CB sequences a trip: their loads are in flight together (a trip waits once for global memory, then walks the chain)
+    for (int hi = on ? (int)nseq - 1 : -1; hi >= 0; hi -= (int)HDR_CB) {
+        uint2 buf[HDR_CB + 1];
 #pragma unroll
-        for (int j = 0; j < 9; j++) { const int idx = hi - j; buf[j] = idx >= 0 ? hseq[idx] : make_uint2(0, 0); }
+        for (int j = 0; j <= (int)HDR_CB; j++) { const int idx = hi - j; buf[j] = idx >= 0 ? hseq[idx] : make_uint2(0, 0); }
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < (int)HDR_CB; j++) {
             const int idx = hi - j;
             if (idx >= 0) {
                 const uint2 cur = buf[j];
@@ -339,7 +341,7 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
                 outv <<= 9 * c;
                 outv |= __shfl_down(outv, 1, WAVE) | __shfl_down(outv, 2, WAVE); // (lane c == 0 of the group: all three)
                 if (c == 0) hst[idx] = outv;
-            } else { (void)__shfl_down(0u, 1, WAVE); (void)__shfl_down(0u, 2, WAVE); }
+            }
         }
     }
     uint32_t fin = st << (8 * c);
