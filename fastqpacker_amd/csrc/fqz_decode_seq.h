@@ -73,12 +73,12 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) // the value of lane 
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
 }
-// bits [lo, lo + n) of the stream (n <= 24) from the window that starts at stream byte wb (a multiple of 4)
+// bits [lo, lo + n) of the stream (n <= 24) from the window that starts at stream byte wb (a multiple of 4); branch-free
 __device__ __forceinline__ uint32_t seq_bits(const uint32_t *win, int wb, int lo, uint32_t n)
 {
-    const uint32_t rel = (uint32_t)(lo - 8 * wb), d = rel >> 5;
+    const uint32_t rel = (uint32_t)(lo - 8 * wb), d = (rel >> 5) & 31u;
     const uint32_t v = __builtin_amdgcn_alignbit(win[d + 1], win[d], rel & 31u);
-    return n ? v & (0xFFFFFFFFu >> (32 - n)) : 0u;
+    return v & ((1u << n) - 1u);
 }
 
 __global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena)
@@ -143,37 +143,42 @@ __global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *
         p -= 17;
     }
     uint32_t o = 0, lit_used = 0, prev_off = 0;
-    for (uint32_t i = 0; i < nseq && !verdict; i++) {
+    const uint32_t cc = c == 3 ? 2u : c; // (the idle lane walks along with the offsets chain: its results are dropped)
+    const uint32_t m_lt2 = cc < 2 ? ~0u : 0u, m_lt1 = cc < 1 ? ~0u : 0u, m_ge1 = cc >= 1 ? ~0u : 0u, m_ge2 = cc >= 2 ? ~0u : 0u;
+    uint32_t bad_profile = 0, bad_data = 0;
+    for (uint32_t i = 0; i < (verdict ? 0u : nseq); i++) { // one rarely-taken branch a step; everything else is straight-line
         if (p - 80 < 8 * wb && wb > 0) window();
-        const uint2 e = T.tab[c == 3 ? 0 : c][st & 63];
+        const uint2 e = T.tab[cc][st & 63];
         const bool last = i + 1 == nseq;
-        const uint32_t xb = c == 3 ? 0u : e.y >> 24, sb = (last || c == 3) ? 0u : (e.x >> 8) & 0xFF;
+        const uint32_t xb = e.y >> 24, sb = last ? 0u : (e.x >> 8) & 0xFF;
         const uint32_t x0 = quad_bcast<0>(xb), x1 = quad_bcast<1>(xb), x2 = quad_bcast<2>(xb);
-        const uint32_t s0 = quad_bcast<0>(sb), s1 = quad_bcast<1>(sb);
-        const uint32_t s2 = quad_bcast<2>(sb);
-        const uint32_t total = x0 + x1 + x2 + s0 + s1 + s2;
-        if (x2 > 24) { verdict = 1; break; }
-        if ((int)total > p) { verdict = 2; break; }
+        const uint32_t s0 = quad_bcast<0>(sb), s1 = quad_bcast<1>(sb), s2 = quad_bcast<2>(sb);
+        const uint32_t xs = x0 + x1 + x2, total = xs + s0 + s1 + s2;
+        bad_profile |= x2 > 24;
+        bad_data |= (int)total > p;
         // stream order (from the top): offset extra bits, match-length extra bits, literal-length extra bits, then the state
         // bits of literal lengths, match lengths, offsets
-        const uint32_t startA = c == 2 ? 0u : (c == 1 ? x2 : x2 + x1);
-        const uint32_t startB = x0 + x1 + x2 + (c == 0 ? 0u : (c == 1 ? s0 : s0 + s1));
-        const uint32_t A = seq_bits(win, wb, p - (int)(startA + xb), xb), B = seq_bits(win, wb, p - (int)(startB + sb), sb);
-        const uint32_t val = (c == 2 ? 1u << xb : e.y & 0xFFFFFFu) + A;
-        if (!last) st = (e.x >> 16) + B;
+        const uint32_t endA = x2 + (x1 & m_lt2) + (x0 & m_lt1);
+        const uint32_t endB = xs + s0 + (s1 & m_ge1) + (s2 & m_ge2);
+        const uint32_t A = seq_bits(win, wb, p - (int)endA, xb), B = seq_bits(win, wb, p - (int)endB, sb);
+        const uint32_t val = (cc == 2 ? 1u << (xb & 31u) : e.y & 0xFFFFFFu) + A;
+        st = last ? st : (e.x >> 16) + B;
         p -= (int)total;
         const uint32_t ll = quad_bcast<0>(val), ml = quad_bcast<1>(val), of_val = quad_bcast<2>(val);
-        uint32_t offset;
-        if (of_val > 3) offset = of_val - 3;
-        else if (of_val == 1 && ll > 0 && i > 0) offset = prev_off; // "the offset of the previous sequence" (of this block)
-        else { verdict = 1; break; }
+        // an explicit offset, or "the offset of the previous sequence" (of this block); anything else is not our profile
+        const bool rep = of_val <= 3;
+        bad_profile |= rep & !((of_val == 1) & (ll > 0) & (i > 0));
+        const uint32_t offset = rep ? prev_off : of_val - 3;
         prev_off = offset;
-        if (ll > ch.regen - lit_used || ll > ch.out_len - o || ml > ch.out_len - o - ll) { verdict = 2; break; }
-        if (offset > o + ll) { verdict = 1; break; } // reaches in front of the block: not ours
+        bad_data |= (ll > ch.regen - lit_used) | (ll > ch.out_len - o) | (ml > ch.out_len - o - ll);
+        bad_profile |= offset > o + ll; // reaches in front of the block: not ours
         if (c == 0) out[i] = make_uint2(ll | (ml << 16), offset);
         lit_used += ll;
         o += ll + ml;
+        if (bad_profile | bad_data) break;
     }
+    if (!verdict && bad_data) verdict = 2;
+    if (!verdict && bad_profile) verdict = 1;
     if (!verdict && (p != 0 || o + (ch.regen - lit_used) != ch.out_len)) verdict = 2;
     if (c == 0) {
         *(uint32_t *)(scr + 2 * FQZ_CHUNK) = verdict ? DSEQ_INVALID : nseq;
@@ -237,7 +242,8 @@ __global__ __launch_bounds__(64) void k_dec_seq_exec(DecInfo *info, const DecChu
             const uint32_t mlj = (uint32_t)__builtin_amdgcn_readlane((int)ml, (int)j), dj = (uint32_t)__builtin_amdgcn_readlane((int)mdst, (int)j);
             const uint32_t fj = (uint32_t)__builtin_amdgcn_readlane((int)q.y, (int)j);
             const uint8_t *ms = S.out + dj - fj;
-            if (fj >= mlj) { for (uint32_t k = lane; k < mlj; k += 64) S.out[dj + k] = ms[k]; }
+            if (mlj <= 64 && fj >= mlj) { if (lane < mlj) S.out[dj + lane] = ms[lane]; } // (nearly all of them)
+            else if (fj >= mlj) { for (uint32_t k = lane; k < mlj; k += 64) S.out[dj + k] = ms[k]; }
             else { for (uint32_t k = lane; k < mlj; k += 64) S.out[dj + k] = ms[k % fj]; } // overlapping: a pattern fill
             SEQ_LDS_ORDER();
         }

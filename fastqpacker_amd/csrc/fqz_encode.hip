@@ -1313,21 +1313,26 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         HIP_TRY(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&e.side2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e.ev_join2, hipEventDisableTiming));
     }
     static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: everything on one stream (standalone kernel times)
-    const hipStream_t sd = dbg_serial ? st : e.side;
+    const hipStream_t sd = dbg_serial ? st : e.side, sd2 = dbg_serial ? st : e.side2; // side: the headers chain; side2: the content checksums
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side, e.ev_fork, 0));
+    HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0));
     // the headers chain (model -> sequences -> entropy over the literals) runs beside the entropy coder of the other streams too
     const uint32_t hgroup_cap = hcap / FQZ_GROUP + e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + e.block_cap + 8 : group_cap;
     PROF(ctx, sd, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, sd, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside));
     PROF(ctx, sd, "k_hdr_seq1", hipLaunchKernelGGL(k_hdr_seq1, dim3((hcap + 15) / 16), dim3(64), 0, sd, info, hcap, hseq, hst, hside));
     PROF(ctx, sd, "k_hdr_seq2", hipLaunchKernelGGL(k_hdr_seq2, dim3(hcap), dim3(64), 0, sd, info, hcap, hseq, hst, hsec, hside));
     PROF(ctx, sd, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, sd, info, hmap, arena, slots, csize, hord, hcap, hlit, hsec, hside));
-    PROF(ctx, sd, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd, info, e.xmap.as<uint4>(), arena, npos, xsum));
+    PROF(ctx, sd2, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd2, info, e.xmap.as<uint4>(), arena, npos, xsum));
+    HIP_TRY(hipEventRecord(e.ev_join2, e.side2));
     HIP_TRY(hipEventRecord(e.ev_join, e.side));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join, 0));
+    HIP_TRY(hipStreamWaitEvent(st, e.ev_join2, 0));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap, hcap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, xsum, arena, d_out, (uint32_t)S_SEQ));

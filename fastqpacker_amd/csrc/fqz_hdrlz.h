@@ -305,47 +305,54 @@ __device__ __forceinline__ void hdr_chain_tables(HdrChainLds &T)
     __builtin_amdgcn_wave_barrier();
 }
 
+template <int K>
+__device__ __forceinline__ uint32_t hdr_quad(uint32_t v) // the value of lane K of this lane's quad (DPP: no LDS round trip)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
+}
 // lane = 4 * (chunk of the wave) + chain (0 literal lengths, 1 match lengths, 2 offsets; 3 idles).
-// hst[i] = ll bits | ml bits << 9 | of bits << 18, each value | nbits << 6; side->pad = the three final states
+// hst[i] = ll bits | ml bits << 9 | of bits << 18, each value | nbits << 6; side->pad = the three final states.
+// A trip takes HDR_CB sequences: their loads are in flight together, their codes and table rows are looked up side by side,
+// and only the state walk itself (one dependent LDS read a step) is serial.
 __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, uint32_t nseq, uint32_t *__restrict__ hst, HdrSide *side, uint32_t c, bool on)
 {
     uint32_t st = 0;
-    bool first = true;
-    // HDR_CB sequences a trip: their loads are in flight together (a trip waits once for global memory, then walks the chain)
+    const uint32_t cc = c < 3 ? c : 2u; // (the idle lane walks along with the offsets chain: its results are dropped)
     for (int hi = on ? (int)nseq - 1 : -1; hi >= 0; hi -= (int)HDR_CB) {
         uint2 buf[HDR_CB + 1];
 #pragma unroll
-        for (int j = 0; j <= (int)HDR_CB; j++) { const int idx = hi - j; buf[j] = idx >= 0 ? hseq[idx] : make_uint2(0, 0); }
+        for (int j = 0; j <= (int)HDR_CB; j++) { const int idx = hi - j; buf[j] = idx >= 0 ? hseq[idx] : make_uint2(3u << 16, 0); }
+        int32_t dnb[HDR_CB], dfs[HDR_CB];
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) {
-            const int idx = hi - j;
-            if (idx >= 0) {
-                const uint2 cur = buf[j];
-                uint32_t code;
-                if (c == 0) { const uint32_t ll = cur.x & 0xFFFFu; code = ll < 64 ? T.ll_code[ll] : (uint32_t)highbit32_d(ll) + 19; }
-                else if (c == 1) { const uint32_t mlb = (cur.x >> 16) - 3; code = mlb < 128 ? T.ml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36; }
-                else code = (uint32_t)highbit32_d(hdr_ofv(cur, buf[j + 1], idx > 0));
-                uint32_t outv = 0;
-                if (c < 3) {
-                    const int32_t dnb = T.dnb[c][code], dfs = T.dfs[c][code];
-                    if (first) { // FSE_initCState2: no output
-                        const uint32_t nb = (uint32_t)(dnb + (1 << 15)) >> 16;
-                        st = T.state[c][(((nb << 16) - (uint32_t)dnb) >> nb) + (uint32_t)dfs];
-                    } else {     // FSE_encodeSymbol
-                        const uint32_t nb = (st + (uint32_t)dnb) >> 16;
-                        outv = (st & ((1u << nb) - 1)) | (nb << 6);
-                        st = T.state[c][(st >> nb) + (uint32_t)dfs];
-                    }
-                }
-                first = false;
-                outv <<= 9 * c;
-                outv |= __shfl_down(outv, 1, WAVE) | __shfl_down(outv, 2, WAVE); // (lane c == 0 of the group: all three)
-                if (c == 0) hst[idx] = outv;
-            }
+            const uint2 cur = buf[j];
+            uint32_t code;
+            if (cc == 0) { const uint32_t ll = cur.x & 0xFFFFu; code = ll < 64 ? T.ll_code[ll] : (uint32_t)highbit32_d(ll) + 19; }
+            else if (cc == 1) { const uint32_t mlb = (cur.x >> 16) - 3; code = mlb < 128 ? T.ml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36; }
+            else code = (uint32_t)highbit32_d(hdr_ofv(cur, buf[j + 1], hi - j > 0));
+            dnb[j] = T.dnb[cc][code];
+            dfs[j] = T.dfs[cc][code];
+        }
+        uint32_t outv[HDR_CB];
+#pragma unroll
+        for (int j = 0; j < (int)HDR_CB; j++) {
+            const bool live = hi - j >= 0;
+            const bool first = hi - j == (int)nseq - 1;
+            // FSE_initCState2 for the last sequence (no output), FSE_encodeSymbol for the others
+            const uint32_t nb0 = (uint32_t)(dnb[j] + (1 << 15)) >> 16;
+            const uint32_t nb = first ? nb0 : (st + (uint32_t)dnb[j]) >> 16;
+            const uint32_t from = first ? (nb0 << 16) - (uint32_t)dnb[j] : st;
+            outv[j] = first ? 0u : ((st & ((1u << nb) - 1)) | (nb << 6));
+            const uint32_t nxt = T.state[cc][((from >> nb) + (uint32_t)dfs[j]) & 63u];
+            st = live ? nxt : st;
+        }
+#pragma unroll
+        for (int j = 0; j < (int)HDR_CB; j++) {
+            const uint32_t v = hdr_quad<0>(outv[j]) | (hdr_quad<1>(outv[j]) << 9) | (hdr_quad<2>(outv[j]) << 18);
+            if (c == 0 && hi - j >= 0) hst[hi - j] = v;
         }
     }
-    uint32_t fin = st << (8 * c);
-    fin |= __shfl_down(fin, 1, WAVE) | __shfl_down(fin, 2, WAVE);
+    const uint32_t fin = hdr_quad<0>(st) | (hdr_quad<1>(st) << 8) | (hdr_quad<2>(st) << 16);
     if (on && c == 0) side->pad = fin;
 }
 
