@@ -1855,15 +1855,23 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             HIP_TRY(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking)); // (a low-priority side stream measured the same)
             HIP_TRY(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
+            HIP_TRY(hipStreamCreateWithFlags(&d.side2, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&d.ev_join2, hipEventDisableTiming));
         }
         static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: one stream (standalone kernel times)
         const hipStream_t sd = dbg_serial ? st : d.side;
         HIP_TRY(hipEventRecord(d.ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(d.side, d.ev_fork, 0));
+        if (any_seq) { // the sequence bit streams need the input only: a chain of serial steps, beside the literals' Huffman decode
+            const hipStream_t s2 = dbg_serial ? st : d.side2;
+            HIP_TRY(hipStreamWaitEvent(d.side2, d.ev_fork, 0));
+            PROF(ctx, s2, "k_dec_seq_fse", hipLaunchKernelGGL(k_dec_seq_fse, dim3((n_chunks + 15) / 16), dim3(64), 0, s2, d_in, info, dch, darena));
+            HIP_TRY(hipEventRecord(d.ev_join2, d.side2));
+        }
         PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, st, d_in, info, dch, darena, dbg, early));
         PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, st, d_in, info, dch, darena, early));
-        if (any_seq) { // headers blocks with sequences: their literals are in the scratch now
-            PROF(ctx, st, "k_dec_seq_fse", hipLaunchKernelGGL(k_dec_seq_fse, dim3((n_chunks + 15) / 16), dim3(64), 0, st, d_in, info, dch, darena));
+        if (any_seq) { // headers blocks with sequences: their literals are in the scratch now, their triples come from side2
+            HIP_TRY(hipStreamWaitEvent(st, d.ev_join2, 0));
             PROF(ctx, st, "k_dec_seq_exec", hipLaunchKernelGGL(k_dec_seq_exec, dim3(n_chunks), dim3(64), 0, st, info, dch, darena));
         }
         PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late));

@@ -1310,7 +1310,11 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     // the content checksums need the streams only: they are hashed on a side stream beside the entropy coder (a chain of
     // memory round trips with a few waves per CU beside a kernel bound by instruction issue) and joined before k_compact
     if (!e.side) {
-        HIP_TRY(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
+        // (the headers chain is a chain of short, partly latency-bound kernels: with priority over the bulk entropy coder its
+        //  serial part runs while that one fills the chip, instead of after it)
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_TRY(hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, prio_hi));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&e.side2, hipStreamNonBlocking));
