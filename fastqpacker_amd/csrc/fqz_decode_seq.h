@@ -187,9 +187,18 @@ __global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *
     }
 }
 
-#define SEQ_LWIN 4096u // literal bytes staged at a time (several batches of sequences)
+// k_dec_seq_exec: a wave per block.  A match almost always copies from the record before it, so the wave keeps only the last
+// SEQ_RING bytes of its output in LDS (a ring, flushed to the stream in 16-byte pieces as it advances) and a small window of
+// the literals: ~6 KiB a wave instead of the block's 16 KiB + literals, which is what decides how many blocks a CU works on at
+// once - the sequences of a block are a serial chain (a match may read what the match before it wrote), every step of it one
+// LDS round trip.  Sequences are taken in batches of up to 64 whose output fits half the ring: a wave scan places all their
+// literal runs at once, then the matches run in order.  Sequences too large for that (a run or a match longer than a
+// quarter of the ring, an offset beyond half of it) go one by one through a slower path that is still exact.
+#define SEQ_RING 4096u
+#define SEQ_RMASK (SEQ_RING - 1u)
+#define SEQ_LWIN 1024u // literal bytes staged at a time
 struct SeqExecLds {
-    uint8_t out[FQZ_CHUNK + 16];
+    uint8_t ring[SEQ_RING];
     uint8_t lw[SEQ_LWIN + 32];
 };
 // LDS operations of one wave execute in issue order: a match may read what the match before it wrote without waiting for
@@ -208,7 +217,15 @@ __global__ __launch_bounds__(64) void k_dec_seq_exec(DecInfo *info, const DecChu
     const uint32_t nseq = *(const uint32_t *)(scr + 2 * FQZ_CHUNK);
     if (nseq == DSEQ_INVALID || nseq > DSEQ_MAX) return;
     const uint32_t n_lit = c.regen, n_out = c.out_len;
-    uint32_t o = 0, lp = 0;
+    uint8_t *dst = arena + c.out_off; // 16-byte aligned (a chunk of a 16-aligned stream)
+    uint32_t o = 0, lp = 0;           // output bytes produced, literals consumed
+    uint32_t flushed = 0;             // (a multiple of 16) output bytes [0, flushed) are in the stream, [flushed, o) only in the ring
+    auto flush = [&]() {              // whole 16-byte pieces below o leave the ring
+        const uint32_t to = o & ~15u;
+        SEQ_LDS_ORDER();
+        for (uint32_t i = flushed + lane * 16; i < to; i += 64 * 16) *(uint4 *)(dst + i) = *(const uint4 *)&S.ring[i & SEQ_RMASK];
+        flushed = to;
+    };
     // the literal window: S.lw[ws_sh + k] = literal ws + k for k < ws_n
     uint32_t ws = 0, ws_n = 0, ws_sh = 0;
     auto stage = [&](uint32_t from) { // literals [from, from + SEQ_LWIN) of the block (as far as they exist), 16-byte pieces
@@ -218,48 +235,84 @@ __global__ __launch_bounds__(64) void k_dec_seq_exec(DecInfo *info, const DecChu
         SEQ_LDS_ORDER();
         ws = from; ws_n = n; ws_sh = from - a0;
     };
-    uint2 q = make_uint2(0, 0);
-    if (lane < nseq) q = seqs[lane];
-    stage(0);
-    for (uint32_t base = 0; base < nseq; base += 64) {
-        const uint32_t cnt = nseq - base < 64 ? nseq - base : 64;
-        uint2 qn = make_uint2(0, 0); // the next batch: in flight while this one runs
-        if (base + 64 + lane < nseq) qn = seqs[base + 64 + lane];
-        const uint32_t ll = q.x & 0xFFFFu, ml = q.x >> 16;
+    // literals [lf, lf + n) -> output [at, at + n), all lanes (n may be large: window by window, the ring flushed as it fills)
+    auto run_all = [&](uint32_t lf, uint32_t at, uint32_t n) {
+        for (uint32_t done = 0; done < n;) {
+            if (lf + done < ws || lf + done >= ws + ws_n) stage(lf + done);
+            uint32_t m = ws + ws_n - (lf + done);
+            m = m < n - done ? m : n - done;
+            m = m < SEQ_RING / 4 ? m : SEQ_RING / 4;
+            o = at + done;
+            flush();
+            for (uint32_t k = lane; k < m; k += 64) S.ring[(at + done + k) & SEQ_RMASK] = S.lw[ws_sh + (lf + done - ws) + k];
+            done += m;
+        }
+        o = at + n;
+    };
+    for (uint32_t base = 0; base < nseq;) {
+        uint2 q = make_uint2(0, 0);
+        if (base + lane < nseq) q = seqs[base + lane];
+        const uint32_t ll = q.x & 0xFFFFu, ml = q.x >> 16, off = q.y;
         const uint32_t in_o = wave_incl_scan(ll + ml), in_l = wave_incl_scan(ll);
-        const uint32_t op = o + in_o - (ll + ml), lq = lp + in_l - ll; // literals [lq, lq + ll) go to out[op, op + ll), the match behind them
-        const uint32_t l_tot = (uint32_t)__builtin_amdgcn_readlane((int)in_l, 63);
-        for (uint32_t w0 = lp; w0 < lp + l_tot;) { // the batch's literals through the window (one pass unless a run is very long)
+        // the batch: the leading sequences whose output fits half the ring, none of them "large"
+        const bool large = ll > SEQ_RING / 4 || ml > SEQ_RING / 4 || off > SEQ_RING / 2;
+        const unsigned long long fits = __ballot(base + lane < nseq && !large && in_o <= SEQ_RING / 2 - 16);
+        const uint32_t cnt = ~fits ? (uint32_t)__builtin_ctzll(~fits) : 64u; // the run of ones from lane 0 up
+        if (cnt == 0) { // one large sequence, by all lanes
+            const uint32_t ll0 = (uint32_t)__builtin_amdgcn_readlane((int)ll, 0), ml0 = (uint32_t)__builtin_amdgcn_readlane((int)ml, 0);
+            const uint32_t off0 = (uint32_t)__builtin_amdgcn_readlane((int)off, 0);
+            run_all(lp, o, ll0);
+            lp += ll0;
+            const uint32_t d0 = o;
+            // the match in pieces: a piece never reads what it writes itself (so the lanes of a piece are independent)
+            const uint32_t piece_max = off0 >= SEQ_RING / 4 ? SEQ_RING / 4 : (off0 >= 64 ? off0 : off0 * (64 / off0));
+            for (uint32_t done = 0; done < ml0;) {
+                const uint32_t m = ml0 - done < piece_max ? ml0 - done : piece_max;
+                o = d0 + done;
+                flush();
+                if (off0 > SEQ_RING / 2) { // the source may have left the ring: it is in the stream (flushed above: at least SEQ_RING / 2 - 16 bytes back)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __builtin_amdgcn_s_waitcnt(0);
+                    for (uint32_t k = lane; k < m; k += 64)
+                        S.ring[(d0 + done + k) & SEQ_RMASK] = __hip_atomic_load(dst + d0 + done + k - off0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    SEQ_LDS_ORDER();
+                    for (uint32_t k = lane; k < m; k += 64) S.ring[(d0 + done + k) & SEQ_RMASK] = S.ring[(d0 + done - off0 + (k % off0)) & SEQ_RMASK];
+                }
+                SEQ_LDS_ORDER();
+                done += m;
+            }
+            o = d0 + ml0;
+            base += 1;
+            continue;
+        }
+        flush(); // (what the last batch produced; the ring has room for this one: half of it, and every source is at most half of it back)
+        const uint32_t l_tot = (uint32_t)__builtin_amdgcn_readlane((int)in_l, (int)cnt - 1), o_tot = (uint32_t)__builtin_amdgcn_readlane((int)in_o, (int)cnt - 1);
+        const uint32_t op = o + in_o - (ll + ml), lq = lp + in_l - ll; // literals [lq, lq + ll) go to output [op, op + ll), the match behind them
+        const uint32_t my_ll = lane < cnt ? ll : 0u;
+        for (uint32_t w0 = lp; w0 < lp + l_tot;) { // the batch's literals through the window
             if (w0 < ws || w0 >= ws + ws_n || (lp + l_tot > ws + ws_n && w0 == lp && ws + ws_n < n_lit)) stage(w0);
             const uint32_t w1 = ws + ws_n < lp + l_tot ? ws + ws_n : lp + l_tot;
-            const uint32_t a = lq > w0 ? lq : w0, b = lq + ll < w1 ? lq + ll : w1; // this lane's part of [w0, w1)
-            for (uint32_t k = a; k < b; k++) S.out[op + (k - lq)] = S.lw[ws_sh + (k - ws)];
+            const uint32_t a = lq > w0 ? lq : w0, b = lq + my_ll < w1 ? lq + my_ll : w1; // this lane's part of [w0, w1)
+            for (uint32_t k = a; k < b; k++) S.ring[(op + (k - lq)) & SEQ_RMASK] = S.lw[ws_sh + (k - ws)];
             w0 = w1;
         }
         SEQ_LDS_ORDER();
         const uint32_t mdst = op + ll;
         for (uint32_t j = 0; j < cnt; j++) { // matches in order: a match may read what the one before it wrote
             const uint32_t mlj = (uint32_t)__builtin_amdgcn_readlane((int)ml, (int)j), dj = (uint32_t)__builtin_amdgcn_readlane((int)mdst, (int)j);
-            const uint32_t fj = (uint32_t)__builtin_amdgcn_readlane((int)q.y, (int)j);
-            const uint8_t *ms = S.out + dj - fj;
-            if (mlj <= 64 && fj >= mlj) { if (lane < mlj) S.out[dj + lane] = ms[lane]; } // (nearly all of them)
-            else if (fj >= mlj) { for (uint32_t k = lane; k < mlj; k += 64) S.out[dj + k] = ms[k]; }
-            else { for (uint32_t k = lane; k < mlj; k += 64) S.out[dj + k] = ms[k % fj]; } // overlapping: a pattern fill
+            const uint32_t fj = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)j);
+            if (mlj <= 64 && fj >= mlj) { if (lane < mlj) S.ring[(dj + lane) & SEQ_RMASK] = S.ring[(dj - fj + lane) & SEQ_RMASK]; } // (nearly all of them)
+            else if (fj >= mlj) { for (uint32_t k = lane; k < mlj; k += 64) S.ring[(dj + k) & SEQ_RMASK] = S.ring[(dj - fj + k) & SEQ_RMASK]; }
+            else { for (uint32_t k = lane; k < mlj; k += 64) S.ring[(dj + k) & SEQ_RMASK] = S.ring[(dj - fj + (k % fj)) & SEQ_RMASK]; } // overlapping: a pattern fill
             SEQ_LDS_ORDER();
         }
-        o += (uint32_t)__builtin_amdgcn_readlane((int)in_o, 63);
+        o += o_tot;
         lp += l_tot;
-        q = qn;
+        base += cnt;
     }
-    for (uint32_t w0 = lp; w0 < n_lit;) { // the literals behind the last match
-        if (w0 < ws || w0 >= ws + ws_n) stage(w0);
-        const uint32_t w1 = ws + ws_n;
-        for (uint32_t k = w0 + lane; k < w1; k += 64) S.out[o + (k - lp)] = S.lw[ws_sh + (k - ws)];
-        w0 = w1;
-    }
+    run_all(lp, o, n_lit - lp); // the literals behind the last match
+    flush();
     SEQ_LDS_ORDER();
-    uint8_t *dst = arena + c.out_off; // 16-byte aligned (a chunk of a 16-aligned stream)
-    const uint32_t full = n_out & ~15u;
-    for (uint32_t i = lane * 16; i < full; i += 64 * 16) *(uint4 *)(dst + i) = *(const uint4 *)&S.out[i];
-    for (uint32_t i = full + lane; i < n_out; i += 64) dst[i] = S.out[i];
+    for (uint32_t i = flushed + lane; i < n_out; i += 64) dst[i] = S.ring[i & SEQ_RMASK];
 }

@@ -1322,12 +1322,15 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     }
     static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: everything on one stream (standalone kernel times)
     const hipStream_t sd = dbg_serial ? st : e.side, sd2 = dbg_serial ? st : e.side2; // side: the headers chain; side2: the content checksums
+    // The headers model fills the chip like the entropy coder does (both are bound by instruction issue: side by side they
+    // only take turns), so it runs in line; what follows it - the FSE state chains, the bit packing, the entropy stage over
+    // the literals - is a chain of short, latency-bound kernels that runs beside the entropy coder of the other streams.
+    const uint32_t hgroup_cap = hcap / FQZ_GROUP + e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + e.block_cap + 8 : group_cap;
+    HIP_TRY(hipEventRecord(e.ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0)); // (the checksums need the streams only)
+    PROF(ctx, st, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, st, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside));
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side, e.ev_fork, 0));
-    HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0));
-    // the headers chain (model -> sequences -> entropy over the literals) runs beside the entropy coder of the other streams too
-    const uint32_t hgroup_cap = hcap / FQZ_GROUP + e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + e.block_cap + 8 : group_cap;
-    PROF(ctx, sd, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, sd, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside));
     PROF(ctx, sd, "k_hdr_seq1", hipLaunchKernelGGL(k_hdr_seq1, dim3((hcap + 15) / 16), dim3(64), 0, sd, info, hcap, hseq, hst, hside));
     PROF(ctx, sd, "k_hdr_seq2", hipLaunchKernelGGL(k_hdr_seq2, dim3(hcap), dim3(64), 0, sd, info, hcap, hseq, hst, hsec, hside));
     PROF(ctx, sd, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, sd, info, hmap, arena, slots, csize, hord, hcap, hlit, hsec, hside));

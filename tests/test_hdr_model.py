@@ -39,6 +39,8 @@ def _hdr_cases():
     yield "mixed lengths", _records([b"inst:%d:%s/1" % (i // 7, b"T" * int(rng.integers(0, 200))) for i in range(2500)])
     yield "long headers (few records per chunk)", _records([b"%d|" % i + b"ACME-SEQ-9000 run=77 lane=3 " * 40 for i in range(300)])
     yield "tail only", _records([bytes(rng.integers(65, 91, 12, dtype=np.uint8)) + b" common tail of some length" for _ in range(3000)])
+    yield "very long headers (offsets beyond the decoder's ring)", _records([b"%07d|" % i + bytes(rng.integers(65, 91, 600, dtype=np.uint8)) * (0 if i % 5 else 1) + b"GATTACA" * 700 for i in range(60)])
+    yield "long runs of one byte (overlapping matches)", _records([b"N" * int(n) for n in rng.integers(1500, 3000, 60)])
     yield "crlf", make_fastq(800, seed=32, crlf=True)
 
 
