@@ -914,7 +914,7 @@ __global__ __launch_bounds__(64) void k_hdr_seq2(const EncInfo *info, uint32_t h
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_entropy_hdr(const EncInfo *info, const uint4 *hmap, const uint8_t *arena, uint8_t *slots, uint32_t *csize,
-                                                     const uint32_t *hord, uint32_t hcap, const uint8_t *hlit, const uint8_t *hsec, const HdrSide *side)
+                                                     const uint32_t *hord, uint32_t hcap, const uint8_t *hlit, const HdrSide *side)
 {
     __shared__ __attribute__((aligned(16))) EntropyLds S;
     __shared__ HdrGroup H;
@@ -926,12 +926,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const uint32_t mk = M - t * FQZ_CHUNK < FQZ_CHUNK ? M - t * FQZ_CHUNK : FQZ_CHUNK, o = hord[chunk + t];
         HdrSide sd = {0, mk, 0, 0};
         if (o < hcap) sd = side[o];
-        H.nseq[t] = sd.nseq; H.n_lit[t] = sd.nseq ? sd.n_lit : mk; H.ssz[t] = sd.sec_len;
+        H.nseq[t] = sd.nseq; H.n_lit[t] = sd.nseq ? sd.n_lit : mk;
         H.lit[t] = sd.nseq ? hlit + (size_t)o * FQZ_CHUNK : src + (size_t)t * FQZ_CHUNK;
-        H.sec[t] = hsec + (size_t)(o < hcap ? o : 0) * HDR_SEQ_CAP;
     }
     __syncthreads();
     entropy_encode_group<true>(S, src, M, 0u, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], 0, nullptr, &H);
+}
+
+// Completes the Compressed blocks of the headers chunks that carry sequences: the Sequences_Section (k_hdr_seq2) goes behind
+// the literals k_entropy_hdr wrote, Block_Size and the chunk's compressed size get their final values.  A wave per chunk.
+__global__ __launch_bounds__(64) void k_hdr_patch(const EncInfo *info, const uint32_t *hlist, uint32_t hcap, const HdrSide *side, const uint8_t *hsec, uint8_t *slots, uint32_t *csize)
+{
+    const uint32_t o = blockIdx.x, lane = threadIdx.x;
+    if (o >= info->n_hchunks || o >= hcap) return;
+    const HdrSide sd = side[o];
+    if (!sd.nseq) return;
+    const uint32_t chunk = hlist[o];
+    uint8_t *slot = slots + (size_t)chunk * FQZ_SLOT;
+    const uint32_t bh = slot[0] | ((uint32_t)slot[1] << 8) | ((uint32_t)slot[2] << 16);
+    if (((bh >> 1) & 3) != 2) return; // the chunk became a Raw block
+    const uint32_t prov = csize[chunk], ssz = sd.sec_len;
+    const uint8_t *sec = hsec + (size_t)o * HDR_SEQ_CAP;
+    for (uint32_t i = lane; i < ssz; i += 64) slot[prov + i] = sec[i];
+    if (lane == 0) {
+        const uint32_t fin = prov + ssz, nb = (bh & 7u) | ((fin - 3u) << 3);
+        slot[0] = (uint8_t)nb; slot[1] = (uint8_t)(nb >> 8); slot[2] = (uint8_t)(nb >> 16);
+        csize[chunk] = fin;
+    }
 }
 
 // Content checksum of every frame (= group): four lanes per group, 16 groups per wave (fqz_xxh.h).  xsum[first chunk] = low 32 bits.
@@ -1310,36 +1331,44 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     // the content checksums need the streams only: they are hashed on a side stream beside the entropy coder (a chain of
     // memory round trips with a few waves per CU beside a kernel bound by instruction issue) and joined before k_compact
     if (!e.side) {
-        // (the headers chain is a chain of short, partly latency-bound kernels: with priority over the bulk entropy coder its
-        //  serial part runs while that one fills the chip, instead of after it)
+        // (the sequence sections are a chain of serial steps: with priority over the bulk entropy coders it is not the last to finish)
         int prio_lo = 0, prio_hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIP_TRY(hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, prio_hi));
+        HIP_TRY(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&e.side2, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_join2, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithPriority(&e.side3, hipStreamNonBlocking, prio_hi));
+        HIP_TRY(hipEventCreateWithFlags(&e.ev_join3, hipEventDisableTiming));
     }
     static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: everything on one stream (standalone kernel times)
-    const hipStream_t sd = dbg_serial ? st : e.side, sd2 = dbg_serial ? st : e.side2; // side: the headers chain; side2: the content checksums
+    // side: the entropy stage over the headers' literals; side2: the content checksums; side3: the headers' sequence sections
+    const hipStream_t sd = dbg_serial ? st : e.side, sd2 = dbg_serial ? st : e.side2, sd3 = dbg_serial ? st : e.side3;
     // The headers model fills the chip like the entropy coder does (both are bound by instruction issue: side by side they
     // only take turns), so it runs in line; what follows it - the FSE state chains, the bit packing, the entropy stage over
     // the literals - is a chain of short, latency-bound kernels that runs beside the entropy coder of the other streams.
     const uint32_t hgroup_cap = hcap / FQZ_GROUP + e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + e.block_cap + 8 : group_cap;
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0)); // (the checksums need the streams only)
+    PROF(ctx, sd2, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd2, info, e.xmap.as<uint4>(), arena, npos, xsum));
+    HIP_TRY(hipEventRecord(e.ev_join2, e.side2));
     PROF(ctx, st, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, st, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside));
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side, e.ev_fork, 0));
-    PROF(ctx, sd, "k_hdr_seq1", hipLaunchKernelGGL(k_hdr_seq1, dim3((hcap + 15) / 16), dim3(64), 0, sd, info, hcap, hseq, hst, hside));
-    PROF(ctx, sd, "k_hdr_seq2", hipLaunchKernelGGL(k_hdr_seq2, dim3(hcap), dim3(64), 0, sd, info, hcap, hseq, hst, hsec, hside));
-    PROF(ctx, sd, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, sd, info, hmap, arena, slots, csize, hord, hcap, hlit, hsec, hside));
-    PROF(ctx, sd2, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd2, info, e.xmap.as<uint4>(), arena, npos, xsum));
-    HIP_TRY(hipEventRecord(e.ev_join2, e.side2));
+    HIP_TRY(hipStreamWaitEvent(e.side3, e.ev_fork, 0));
+    // the serial part (FSE state chains, then the bit packing) and the entropy stage over the headers' literals need the model
+    // only, not each other: k_hdr_patch joins them
+    PROF(ctx, sd3, "k_hdr_seq1", hipLaunchKernelGGL(k_hdr_seq1, dim3((hcap + 15) / 16), dim3(64), 0, sd3, info, hcap, hseq, hst, hside));
+    PROF(ctx, sd3, "k_hdr_seq2", hipLaunchKernelGGL(k_hdr_seq2, dim3(hcap), dim3(64), 0, sd3, info, hcap, hseq, hst, hsec, hside));
+    HIP_TRY(hipEventRecord(e.ev_join3, e.side3));
+    PROF(ctx, sd, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, sd, info, hmap, arena, slots, csize, hord, hcap, hlit, hside));
     HIP_TRY(hipEventRecord(e.ev_join, e.side));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join, 0));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join2, 0));
+    HIP_TRY(hipStreamWaitEvent(st, e.ev_join3, 0));
+    PROF(ctx, st, "k_hdr_patch", hipLaunchKernelGGL(k_hdr_patch, dim3(hcap), dim3(64), 0, st, info, hlist, hcap, hside, hsec, slots, csize));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap, hcap));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, xsum, arena, d_out, (uint32_t)S_SEQ));

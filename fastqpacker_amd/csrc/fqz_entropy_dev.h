@@ -347,15 +347,17 @@ __device__ __forceinline__ void load_chunk_syms(EntropyLds &S, const uint8_t *sr
 // Every group is a zstd frame of its own (FQZ-H2): its last chunk carries the Last_Block bit.  force_raw: the 2-bit packed
 // bases are Raw blocks by definition - no histogram, no table, no bit counting.
 //
-// HDR (headers stream, fqz_hdrlz.h): chunk k has been modelled into H->nseq[k] sequences (their Sequences_Section: H->sec[k],
-// H->ssz[k] bytes) and H->n_lit[k] literals at H->lit[k]; the table is built over the literals, the block carries the
-// Huffman-coded literals followed by the sequences.  A chunk without sequences has lit = the chunk itself.
+// HDR (headers stream, fqz_hdrlz.h): chunk k has been modelled into H->nseq[k] sequences and H->n_lit[k] literals at
+// H->lit[k]; the table is built over the literals, the block carries the Huffman-coded literals followed by the
+// Sequences_Section.  That section comes out of a serial chain (the FSE states) that runs beside this kernel: the block is
+// written here WITHOUT it (its size counts with the bound HDR_SSZ_BOUND when the block is judged against the Raw block - the
+// FQZ-H2 rule, oracle encode_group_chunks) and k_hdr_patch appends it and completes the block header.  A chunk without
+// sequences has lit = the chunk itself.
 struct HdrGroup {
     const uint8_t *lit[FQZ_GROUP];
-    const uint8_t *sec[FQZ_GROUP];
-    uint32_t n_lit[FQZ_GROUP], nseq[FQZ_GROUP], ssz[FQZ_GROUP];
+    uint32_t n_lit[FQZ_GROUP], nseq[FQZ_GROUP];
 };
-#define HDR_SEC_OVERFLOW 0xFFFFFFFFu
+#define HDR_SSZ_BOUND(n) (((n) < 128u ? 2u : 3u) + ((n) * 66u + 18u + 7u) / 8u)
 
 template <bool HDR>
 __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const uint32_t M, const uint32_t force_raw, uint8_t *slot0, uint32_t *csize0,
@@ -638,8 +640,7 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
         uint32_t cmode = mode; // 2 = Huffman with the group table, anything else = raw
         const uint32_t nseq = HDR ? H->nseq[k] : 0u;
         const uint32_t ml = HDR ? H->n_lit[k] : mk;       // literals of the block (== the chunk when there are no sequences)
-        const uint32_t sec_sz = nseq ? H->ssz[k] : 1u;       // Sequences_Section bytes (Number_of_Sequences = 0: one byte)
-        if (HDR && sec_sz == HDR_SEC_OVERFLOW) cmode = 0;
+        const uint32_t sec_sz = nseq ? HDR_SSZ_BOUND(nseq) : 1u; // Sequences_Section bytes as judged (Number_of_Sequences = 0: one byte)
         if (cmode == 2) {
             ChunkSyms C;
             load_chunk_syms(S, HDR ? H->lit[k] : csrc, ml, C);
@@ -694,8 +695,7 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
                     }
                     for (uint32_t q = 0; q < 4; q++) { S.misc[8 + q] = pos; pos += ssz[q]; } // stream start bytes
                     if (!nseq) o[pos] = 0;                                                     // Number_of_Sequences = 0
-                    S.misc[12] = pos + sec_sz;
-                    S.misc[15] = pos;
+                    S.misc[12] = pos + (nseq ? 0u : 1u);                                       // (sequences: appended by k_hdr_patch)
                     S.misc[14] = 3 + lh; // tree offset
                 }
             }
@@ -738,12 +738,6 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
                     if (fill > 32) atomicOr(&S.out[word + 1], (uint32_t)(acc >> 32));
                 }
                 __syncthreads();
-                if (HDR && nseq) { // the Sequences_Section behind the literals
-                    uint8_t *o8 = (uint8_t *)S.out + S.misc[15];
-                    const uint8_t *sec = H->sec[k];
-                    for (uint32_t i = t; i < sec_sz; i += 256) o8[i] = sec[i];
-                    __syncthreads();
-                }
                 const uint32_t total = S.misc[12];
                 uint32_t *slot32 = (uint32_t *)slot;
                 for (uint32_t i = t; i < (total + 3) / 4; i += 256) slot32[i] = S.out[i];
@@ -754,7 +748,7 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
             }
             __syncthreads();
         }
-        if (HDR && mode != 2 && nseq && sec_sz != HDR_SEC_OVERFLOW) { // no table for this group: the literals of a block with sequences travel raw
+        if (HDR && mode != 2 && nseq) { // no table for this group: the literals of a block with sequences travel raw
             const uint32_t lh = ml < 32 ? 1u : (ml < 4096 ? 2u : 3u), content = lh + ml + sec_sz;
             if (content < mk) {
                 if (t == 0) {
@@ -762,11 +756,10 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
                     slot[0] = (uint8_t)bh; slot[1] = (uint8_t)(bh >> 8); slot[2] = (uint8_t)(bh >> 16);
                     const uint32_t v = lh == 1 ? ml << 3 : (((lh == 2 ? 1u : 3u) << 2) | (ml << 4)); // Raw_Literals_Block, size format by lh
                     for (uint32_t q = 0; q < lh; q++) slot[3 + q] = (uint8_t)(v >> (8 * q));
-                    csize0[k] = 3 + content;
+                    csize0[k] = 3 + lh + ml; // (the section follows: k_hdr_patch)
                 }
-                const uint8_t *lit = H->lit[k], *sec = H->sec[k];
+                const uint8_t *lit = H->lit[k];
                 for (uint32_t i = t; i < ml; i += 256) slot[3 + lh + i] = lit[i];
-                for (uint32_t i = t; i < sec_sz; i += 256) slot[3 + lh + ml + i] = sec[i];
                 continue;
             }
         }

@@ -501,6 +501,7 @@ typedef struct {
     const hseq *sq; uint32_t nseq;
 } gchunk;
 
+#define HDR_SSZ_BOUND(n) (((n) < 128 ? 2u : 3u) + ((n) * 66u + 18u + 7u) / 8u) /* count + modes byte + bit stream: <= 66 bits a sequence, 17 flush bits, the end mark */
 static size_t encode_group_chunks(const gchunk *ch, int nch, int force_raw, uint8_t *dst)
 {
     uint32_t count[256] = {0};
@@ -566,7 +567,12 @@ static size_t encode_group_chunks(const gchunk *ch, int nch, int force_raw, uint
             lh = m < 32 ? 1 : (m < 4096 ? 2 : 3);
             content = lh + m + ssz;
         }
-        if ((!huff && !nseq) || content >= mk) { out += raw_block(ch[k].raw, mk, lastblk, out); continue; }
+        /* Raw block when coding does not pay.  With sequences the test uses an upper bound of the section size
+         * (66 bits a sequence) instead of the section itself: a parallel encoder then places and codes the literals of a
+         * block without waiting for the serial FSE state chains of its sequences (FQZ-H2 rule; costs nothing unless a
+         * block is within a few hundred bytes of not compressing at all) */
+        const size_t judged = nseq ? content - ssz + HDR_SSZ_BOUND(nseq) : content;
+        if ((!huff && !nseq) || judged >= mk) { out += raw_block(ch[k].raw, mk, lastblk, out); continue; }
         put_block_header(out, lastblk, 2, (uint32_t)content);
         uint8_t *op = out + 3;
         if (!huff) { /* Raw_Literals_Block */
