@@ -279,9 +279,38 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
 //                    places them, LDS atomics merge them
 // ---------------------------------------------------------------------------------------------
 #define HDR_CB 24u // sequences per trip of hdr_seq_chains
+// FSE_encodeSymbol as ONE table read: tr[row of the symbol + state] = next state | bits to emit << 8 (states count from 0:
+// the real state is that + the table size, whose low `bits` bits are the same); init[symbol] = FSE_initCState2
+#define HDR_TR_LL 0u
+#define HDR_TR_ML (36u * 64u)
+#define HDR_TR_OF (HDR_TR_ML + 53u * 64u)
+#define HDR_TR_N (HDR_TR_OF + 29u * 32u)
+struct HdrTrans { uint16_t tr[HDR_TR_N]; uint8_t init[3][56]; };
+template <int NSYM>
+constexpr void hdr_make_trans(const short (&norm)[NSYM], int log, uint16_t *tr, uint8_t *init)
+{
+    const HdrCt ct = hdr_make_ct(norm, log);
+    const int size = 1 << log;
+    for (int sy = 0; sy < NSYM; sy++) {
+        for (int st = 0; st < size; st++) {
+            const uint32_t full = (uint32_t)(st + size), nb = (full + (uint32_t)ct.dnb[sy]) >> 16;
+            tr[sy * size + st] = (uint16_t)((ct.state[(full >> nb) + (uint32_t)ct.dfs[sy]] - size) | (nb << 8));
+        }
+        const uint32_t nb0 = (uint32_t)(ct.dnb[sy] + (1 << 15)) >> 16;
+        init[sy] = (uint8_t)(ct.state[(((nb0 << 16) - (uint32_t)ct.dnb[sy]) >> nb0) + (uint32_t)ct.dfs[sy]] - size);
+    }
+}
+constexpr HdrTrans hdr_make_all_trans()
+{
+    HdrTrans t{};
+    hdr_make_trans(HDR_LL_NORM, 6, t.tr + HDR_TR_LL, t.init[0]);
+    hdr_make_trans(HDR_ML_NORM, 6, t.tr + HDR_TR_ML, t.init[1]);
+    hdr_make_trans(HDR_OF_NORM, 5, t.tr + HDR_TR_OF, t.init[2]);
+    return t;
+}
+__constant__ const HdrTrans c_hdr_trans = hdr_make_all_trans();
 struct HdrChainLds {
-    uint16_t state[3][64];
-    int32_t dnb[3][56], dfs[3][56];
+    HdrTrans t;
     uint8_t ll_code[64], ml_code[128];
 };
 __device__ __forceinline__ uint32_t hdr_ofv(const uint2 cur, const uint2 prev, bool has_prev)
@@ -293,11 +322,9 @@ __device__ __forceinline__ uint32_t hdr_ofv(const uint2 cur, const uint2 prev, b
 __device__ __forceinline__ void hdr_chain_tables(HdrChainLds &T)
 {
     const uint32_t lane = threadIdx.x;
-    const HdrCt *ct[3] = {&c_hdr_ll, &c_hdr_ml, &c_hdr_of};
-    for (int c = 0; c < 3; c++) {
-        T.state[c][lane] = ct[c]->state[lane];
-        if (lane < 53) { T.dnb[c][lane] = ct[c]->dnb[lane]; T.dfs[c][lane] = ct[c]->dfs[lane]; }
-    }
+    const uint32_t *src = (const uint32_t *)&c_hdr_trans;
+    uint32_t *dst = (uint32_t *)&T.t;
+    for (uint32_t i = lane; i < sizeof(HdrTrans) / 4; i += 64) dst[i] = src[i];
     T.ll_code[lane] = c_hll_code[lane];
     T.ml_code[lane] = c_hml_code[lane];
     T.ml_code[64 + lane] = c_hml_code[64 + lane];
@@ -322,7 +349,8 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
         uint2 buf[HDR_CB + 1];
 #pragma unroll
         for (int j = 0; j <= (int)HDR_CB; j++) { const int idx = hi - j; buf[j] = idx >= 0 ? hseq[idx] : make_uint2(3u << 16, 0); }
-        int32_t dnb[HDR_CB], dfs[HDR_CB];
+        uint32_t row[HDR_CB]; // table row of this lane's chain for the symbol of sequence hi - j
+        const uint32_t tbase = cc == 0 ? HDR_TR_LL : (cc == 1 ? HDR_TR_ML : HDR_TR_OF), tshift = cc == 2 ? 5u : 6u;
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) {
             const uint2 cur = buf[j];
@@ -330,21 +358,16 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
             if (cc == 0) { const uint32_t ll = cur.x & 0xFFFFu; code = ll < 64 ? T.ll_code[ll] : (uint32_t)highbit32_d(ll) + 19; }
             else if (cc == 1) { const uint32_t mlb = (cur.x >> 16) - 3; code = mlb < 128 ? T.ml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36; }
             else code = (uint32_t)highbit32_d(hdr_ofv(cur, buf[j + 1], hi - j > 0));
-            dnb[j] = T.dnb[cc][code];
-            dfs[j] = T.dfs[cc][code];
+            row[j] = code;
         }
+        if (hi == (int)nseq - 1) st = T.t.init[cc][row[0]]; // the last sequence opens the chain: no output
         uint32_t outv[HDR_CB];
 #pragma unroll
-        for (int j = 0; j < (int)HDR_CB; j++) {
-            const bool live = hi - j >= 0;
-            const bool first = hi - j == (int)nseq - 1;
-            // FSE_initCState2 for the last sequence (no output), FSE_encodeSymbol for the others
-            const uint32_t nb0 = (uint32_t)(dnb[j] + (1 << 15)) >> 16;
-            const uint32_t nb = first ? nb0 : (st + (uint32_t)dnb[j]) >> 16;
-            const uint32_t from = first ? (nb0 << 16) - (uint32_t)dnb[j] : st;
+        for (int j = 0; j < (int)HDR_CB; j++) { // the walk: one dependent LDS read a step
+            const bool live = hi - j >= 0, first = hi - j == (int)nseq - 1;
+            const uint32_t e = T.t.tr[tbase + (row[j] << tshift) + st], nb = e >> 8;
             outv[j] = first ? 0u : ((st & ((1u << nb) - 1)) | (nb << 6));
-            const uint32_t nxt = T.state[cc][((from >> nb) + (uint32_t)dfs[j]) & 63u];
-            st = live ? nxt : st;
+            st = (live && !first) ? (e & 0xFFu) : st;
         }
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) {
