@@ -84,6 +84,7 @@ __device__ __forceinline__ uint32_t seq_bits(const uint32_t *win, int wb, int lo
 __global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena)
 {
     __shared__ SeqFseLds T;
+    __builtin_amdgcn_s_setprio(3); // a serial chain of short steps beside kernels that fill every issue slot: its waves go first
     const uint32_t lane = threadIdx.x, g = lane >> 2, c = lane & 3, id = blockIdx.x * 16 + g;
     if (info->status) return;
     DecChunk ch;
@@ -208,6 +209,7 @@ struct SeqExecLds {
 __global__ __launch_bounds__(64) void k_dec_seq_exec(DecInfo *info, const DecChunk *chunks, uint8_t *arena)
 {
     __shared__ __attribute__((aligned(16))) SeqExecLds S;
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x, id = blockIdx.x;
     if (id >= info->n_chunks || info->status) return;
     const DecChunk c = chunks[id];

@@ -896,6 +896,7 @@ __global__ __launch_bounds__(256) void k_hdr_model(const EncInfo *info, const Bl
 __global__ __launch_bounds__(64) void k_hdr_seq1(const EncInfo *info, uint32_t hcap, const uint2 *hseq, uint32_t *hst, HdrSide *side)
 {
     __shared__ HdrChainLds T;
+    __builtin_amdgcn_s_setprio(3); // a serial chain of short steps beside kernels that fill every issue slot: its waves go first
     const uint32_t lane = threadIdx.x, o = blockIdx.x * 16 + (lane >> 2), c = lane & 3;
     const uint32_t nh = info->n_hchunks < hcap ? info->n_hchunks : hcap;
     if (blockIdx.x * 16 >= nh) return;
@@ -907,6 +908,7 @@ __global__ __launch_bounds__(64) void k_hdr_seq1(const EncInfo *info, uint32_t h
 __global__ __launch_bounds__(64) void k_hdr_seq2(const EncInfo *info, uint32_t hcap, const uint2 *hseq, const uint32_t *hst, uint8_t *hsec, HdrSide *side)
 {
     __shared__ __attribute__((aligned(16))) HdrPackLds S;
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t o = blockIdx.x;
     if (o >= info->n_hchunks || o >= hcap) return;
     const uint32_t nseq = side[o].nseq;
