@@ -279,23 +279,26 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
 //                    places them, LDS atomics merge them
 // ---------------------------------------------------------------------------------------------
 #define HDR_CB 24u // sequences per trip of hdr_seq_chains
-// FSE_encodeSymbol as ONE table read: tr[row of the symbol + state] = next state | bits to emit << 8 (states count from 0:
-// the real state is that + the table size, whose low `bits` bits are the same); init[symbol] = FSE_initCState2
+// FSE_encodeSymbol as ONE table read: tr[row of the symbol + state] = next state (states count from 0: the real state is
+// that + the table size); the number of bits a step emits, (state + deltaNbBits[symbol]) >> 16, is not on the chain;
+// init[symbol] = FSE_initCState2.  One byte an entry: the tables of a wave fit the LDS a CU has left beside eight workgroups
+// of the entropy coder, so the chains start at once instead of waiting for one of those to retire
 #define HDR_TR_LL 0u
 #define HDR_TR_ML (36u * 64u)
 #define HDR_TR_OF (HDR_TR_ML + 53u * 64u)
 #define HDR_TR_N (HDR_TR_OF + 29u * 32u)
-struct HdrTrans { uint16_t tr[HDR_TR_N]; uint8_t init[3][56]; };
+struct HdrTrans { uint8_t tr[HDR_TR_N]; uint8_t init[3][56]; int32_t dnb[3][56]; };
 template <int NSYM>
-constexpr void hdr_make_trans(const short (&norm)[NSYM], int log, uint16_t *tr, uint8_t *init)
+constexpr void hdr_make_trans(const short (&norm)[NSYM], int log, uint8_t *tr, uint8_t *init, int32_t *dnb)
 {
     const HdrCt ct = hdr_make_ct(norm, log);
     const int size = 1 << log;
     for (int sy = 0; sy < NSYM; sy++) {
         for (int st = 0; st < size; st++) {
             const uint32_t full = (uint32_t)(st + size), nb = (full + (uint32_t)ct.dnb[sy]) >> 16;
-            tr[sy * size + st] = (uint16_t)((ct.state[(full >> nb) + (uint32_t)ct.dfs[sy]] - size) | (nb << 8));
+            tr[sy * size + st] = (uint8_t)(ct.state[(full >> nb) + (uint32_t)ct.dfs[sy]] - size);
         }
+        dnb[sy] = ct.dnb[sy];
         const uint32_t nb0 = (uint32_t)(ct.dnb[sy] + (1 << 15)) >> 16;
         init[sy] = (uint8_t)(ct.state[(((nb0 << 16) - (uint32_t)ct.dnb[sy]) >> nb0) + (uint32_t)ct.dfs[sy]] - size);
     }
@@ -303,9 +306,9 @@ constexpr void hdr_make_trans(const short (&norm)[NSYM], int log, uint16_t *tr, 
 constexpr HdrTrans hdr_make_all_trans()
 {
     HdrTrans t{};
-    hdr_make_trans(HDR_LL_NORM, 6, t.tr + HDR_TR_LL, t.init[0]);
-    hdr_make_trans(HDR_ML_NORM, 6, t.tr + HDR_TR_ML, t.init[1]);
-    hdr_make_trans(HDR_OF_NORM, 5, t.tr + HDR_TR_OF, t.init[2]);
+    hdr_make_trans(HDR_LL_NORM, 6, t.tr + HDR_TR_LL, t.init[0], t.dnb[0]);
+    hdr_make_trans(HDR_ML_NORM, 6, t.tr + HDR_TR_ML, t.init[1], t.dnb[1]);
+    hdr_make_trans(HDR_OF_NORM, 5, t.tr + HDR_TR_OF, t.init[2], t.dnb[2]);
     return t;
 }
 __constant__ const HdrTrans c_hdr_trans = hdr_make_all_trans();
@@ -349,8 +352,9 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
         uint2 buf[HDR_CB + 1];
 #pragma unroll
         for (int j = 0; j <= (int)HDR_CB; j++) { const int idx = hi - j; buf[j] = idx >= 0 ? hseq[idx] : make_uint2(3u << 16, 0); }
-        uint32_t row[HDR_CB]; // table row of this lane's chain for the symbol of sequence hi - j
-        const uint32_t tbase = cc == 0 ? HDR_TR_LL : (cc == 1 ? HDR_TR_ML : HDR_TR_OF), tshift = cc == 2 ? 5u : 6u;
+        uint32_t row[HDR_CB]; // the symbol of this lane's chain for sequence hi - j
+        uint32_t dnb[HDR_CB];
+        const uint32_t tbase = cc == 0 ? HDR_TR_LL : (cc == 1 ? HDR_TR_ML : HDR_TR_OF), tshift = cc == 2 ? 5u : 6u, tsize = 1u << tshift;
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) {
             const uint2 cur = buf[j];
@@ -359,15 +363,16 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
             else if (cc == 1) { const uint32_t mlb = (cur.x >> 16) - 3; code = mlb < 128 ? T.ml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36; }
             else code = (uint32_t)highbit32_d(hdr_ofv(cur, buf[j + 1], hi - j > 0));
             row[j] = code;
+            dnb[j] = (uint32_t)T.t.dnb[cc][code];
         }
         if (hi == (int)nseq - 1) st = T.t.init[cc][row[0]]; // the last sequence opens the chain: no output
         uint32_t outv[HDR_CB];
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) { // the walk: one dependent LDS read a step
             const bool live = hi - j >= 0, first = hi - j == (int)nseq - 1;
-            const uint32_t e = T.t.tr[tbase + (row[j] << tshift) + st], nb = e >> 8;
+            const uint32_t nxt = T.t.tr[tbase + (row[j] << tshift) + st], nb = (st + tsize + dnb[j]) >> 16;
             outv[j] = first ? 0u : ((st & ((1u << nb) - 1)) | (nb << 6));
-            st = (live && !first) ? (e & 0xFFu) : st;
+            st = (live && !first) ? nxt : st;
         }
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) {
@@ -379,33 +384,51 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
     if (on && c == 0) side->pad = fin;
 }
 
-#define HDR_STAGE_WORDS ((HDR_SEQ_CAP + 16) / 4)
-struct HdrPackLds { uint32_t w[HDR_STAGE_WORDS]; uint8_t ll_code[64], ml_code[128]; };
-__device__ __forceinline__ void hdr_or_bits(uint32_t *w, uint32_t bitpos, unsigned long long v, uint32_t n)
+#define HDR_PW 160u // dwords of the packing window: a batch of 64 sequences is at most 64 x 66 bits = 132 dwords
+struct HdrPackLds { uint32_t w[HDR_PW]; uint8_t ll_code[64], ml_code[128]; };
+__device__ __forceinline__ void hdr_or_bits(uint32_t *w, uint32_t bitpos, unsigned long long v, uint32_t n) // bitpos: relative to the window
 {
     if (!n) return;
     const uint32_t i = bitpos >> 5, sh = bitpos & 31;
-    if (i + 3 > HDR_STAGE_WORDS) return; // a section that long is discarded anyway (HDR_OVERFLOW)
     atomicOr(&w[i], (uint32_t)(v << sh));
     const unsigned long long hi = sh ? v >> (32 - sh) : v >> 16 >> 16;
     if (sh + n > 32) atomicOr(&w[i + 1], (uint32_t)hi);
     if (sh + n > 64) atomicOr(&w[i + 2], (uint32_t)(hi >> 32));
 }
-// one wave per chunk
+// one wave per chunk.  The section is assembled a batch of 64 sequences at a time in a small LDS window; the dwords a batch
+// completes go to dst at once (dst is dword aligned), the one it leaves open stays for the next batch.
 __device__ void hdr_seq_pack(HdrPackLds &S, const uint2 *__restrict__ hseq, uint32_t nseq, const uint32_t *__restrict__ hst, uint8_t *__restrict__ dst, HdrSide *side)
 {
     const uint32_t lane = threadIdx.x;
     S.ll_code[lane] = c_hll_code[lane];
     S.ml_code[lane] = c_hml_code[lane];
     S.ml_code[64 + lane] = c_hml_code[64 + lane];
-    const uint32_t est_words = (nseq * 9u + 64u) / 4u < HDR_STAGE_WORDS ? (nseq * 9u + 64u) / 4u : HDR_STAGE_WORDS; // <= 66 bits a sequence
-    for (uint32_t i = lane; i < est_words; i += 64) S.w[i] = 0;
+    for (uint32_t i = lane; i < HDR_PW; i += 64) S.w[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     // Number_of_Sequences (1 or 2 bytes: nseq < 0x7F00) and the modes byte
     const uint32_t hb = nseq < 128 ? 2u : 3u;
     if (lane == 0) S.w[0] = nseq < 128 ? nseq : (((nseq >> 8) + 128) | ((nseq & 255) << 8));
-    uint32_t P = 8 * hb;
+    uint32_t P = 8 * hb; // bits of the section so far
+    uint32_t w0 = 0;     // dword of the section that S.w[0] holds
+    uint32_t *dst32 = (uint32_t *)dst;
+    auto drain = [&]() { // whole dwords below P leave; the open one moves to the front
+        const uint32_t full = (P >> 5) - w0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t keep[3];
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) { const uint32_t i = lane + 64 * r; keep[r] = i < HDR_PW ? S.w[i] : 0u; }
+        const uint32_t open = S.w[full < HDR_PW ? full : 0];
+#pragma unroll
+        for (uint32_t r = 0; r < 3; r++) { const uint32_t i = lane + 64 * r; if (i < full && w0 + i < HDR_SEQ_CAP / 4) dst32[w0 + i] = keep[r]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < HDR_PW; i += 64) S.w[i] = (i == 0) ? open : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        w0 += full;
+    };
     for (int top = (int)nseq - 1; top >= 0; top -= 64) {
         const int i = top - (int)lane;
         uint32_t n1 = 0, n2 = 0;
@@ -428,21 +451,22 @@ __device__ void hdr_seq_pack(HdrPackLds &S, const uint2 *__restrict__ hseq, uint
             n2 = lb + mb + oc;
         }
         const uint32_t incl = wave_incl_scan(n1 + n2);
-        const uint32_t at = P + incl - (n1 + n2);
+        const uint32_t at = P - 32 * w0 + incl - (n1 + n2);
         hdr_or_bits(S.w, at, v1, n1);
         hdr_or_bits(S.w, at + n1, v2, n2);
         P += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        drain();
     }
     if (lane == 0) { // FSE_flushCState: match lengths, offsets, literal lengths; then the end mark
         const uint32_t fin = side->pad;
         const unsigned long long tail = (unsigned long long)((fin >> 8) & 63) | ((unsigned long long)((fin >> 16) & 31) << 6) | ((unsigned long long)(fin & 63) << 11) | (1ull << 17);
-        hdr_or_bits(S.w, P, tail, 18);
+        hdr_or_bits(S.w, P - 32 * w0, tail, 18);
     }
     P += 18;
     const uint32_t bytes = (P + 7) >> 3;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (bytes >= FQZ_CHUNK) { if (lane == 0) side->sec_len = HDR_OVERFLOW; return; } // a section that long cannot beat the Raw block
-    for (uint32_t i = lane; i < (bytes + 3) / 4; i += 64) ((uint32_t *)dst)[i] = S.w[i];
+    if (bytes >= FQZ_CHUNK) { if (lane == 0) side->sec_len = HDR_OVERFLOW; return; } // (cannot happen for a block judged compressible: HDR_SSZ_BOUND)
+    if (lane < 2 && w0 + lane < HDR_SEQ_CAP / 4 && 4 * (w0 + lane) < bytes) dst32[w0 + lane] = S.w[lane];
     if (lane == 0) side->sec_len = bytes;
 }
