@@ -715,13 +715,14 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
 #define PUT2(s1, s2) do { uint32_t e1 = S.ctab[(s1)], e2 = S.ctab[(s2)];                         \
                           acc |= (unsigned long long)(e1 & 0xFFFF) << fill; fill += e1 >> 16;  \
                           acc |= (unsigned long long)(e2 & 0xFFFF) << fill; fill += e2 >> 16;  \
-                          atomicOr(&S.out[word], (uint32_t)acc);                               \
                           uint32_t adv = fill >> 5; /* 0 or 1 whole words completed */         \
+                          if (adv) atomicOr(&S.out[word], (uint32_t)acc); /* (its first bits may be a neighbour's) */ \
                           acc >>= (adv << 5); word += adv; fill &= 31; } while (0)
 #define PUT1(s1) do { uint32_t e1 = S.ctab[(s1)];                                                \
                       acc |= (unsigned long long)(e1 & 0xFFFF) << fill; fill += e1 >> 16;      \
-                      atomicOr(&S.out[word], (uint32_t)acc);                                   \
-                      uint32_t adv = fill >> 5; acc >>= (adv << 5); word += adv; fill &= 31; } while (0)
+                      uint32_t adv = fill >> 5;                                                \
+                      if (adv) atomicOr(&S.out[word], (uint32_t)acc);                          \
+                      acc >>= (adv << 5); word += adv; fill &= 31; } while (0)
 #pragma unroll
                     for (int d = 15; d >= 0; d--) {
                         if (4u * d + 4 <= C.cnt) {

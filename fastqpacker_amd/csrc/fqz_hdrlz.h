@@ -279,36 +279,38 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
 //                    places them, LDS atomics merge them
 // ---------------------------------------------------------------------------------------------
 #define HDR_CB 24u // sequences per trip of hdr_seq_chains
-// FSE_encodeSymbol as ONE table read: tr[row of the symbol + state] = next state (states count from 0: the real state is
-// that + the table size); the number of bits a step emits, (state + deltaNbBits[symbol]) >> 16, is not on the chain;
-// init[symbol] = FSE_initCState2.  One byte an entry: the tables of a wave fit the LDS a CU has left beside eight workgroups
-// of the entropy coder, so the chains start at once instead of waiting for one of those to retire
-#define HDR_TR_LL 0u
-#define HDR_TR_ML (36u * 64u)
-#define HDR_TR_OF (HDR_TR_ML + 53u * 64u)
-#define HDR_TR_N (HDR_TR_OF + 29u * 32u)
-struct HdrTrans { uint8_t tr[HDR_TR_N]; uint8_t init[3][56]; int32_t dnb[3][56]; };
+// FSE_encodeSymbol WITHOUT a memory access on the state chain.  A symbol with normalised count c owns c entries of the
+// state table (c <= 4 in the predefined distributions), and the step picks one of them:
+//   nb = (state + deltaNbBits[sym]) >> 16,  k = (state >> nb) - c,  next state = entry k of the symbol
+// so what the chain needs per sequence - the symbol's (up to) four next states packed in one word, its deltaNbBits and c -
+// is looked up beforehand, for a whole trip of sequences side by side, and the walk itself is seven register operations a
+// step.  (The chains run beside the entropy coder, which saturates the LDS pipeline: a dependent LDS read a step took four
+// times as long there as on an idle chip.)  States count from 0: the real state is that + the table size.
+struct HdrTrans { uint32_t cand[3][56]; int32_t dnb[3][56]; uint8_t cnt[3][56], init[3][56]; };
 template <int NSYM>
-constexpr void hdr_make_trans(const short (&norm)[NSYM], int log, uint8_t *tr, uint8_t *init, int32_t *dnb)
+constexpr void hdr_make_trans(const short (&norm)[NSYM], int log, uint32_t *cand, int32_t *dnb, uint8_t *cnt, uint8_t *init)
 {
     const HdrCt ct = hdr_make_ct(norm, log);
     const int size = 1 << log;
+    int cumul = 0;
     for (int sy = 0; sy < NSYM; sy++) {
-        for (int st = 0; st < size; st++) {
-            const uint32_t full = (uint32_t)(st + size), nb = (full + (uint32_t)ct.dnb[sy]) >> 16;
-            tr[sy * size + st] = (uint8_t)(ct.state[(full >> nb) + (uint32_t)ct.dfs[sy]] - size);
-        }
+        const int c = norm[sy] == -1 ? 1 : norm[sy];
+        uint32_t packed = 0;
+        for (int k = 0; k < c && k < 4; k++) packed |= (uint32_t)(ct.state[cumul + k] - size) << (8 * k);
+        cand[sy] = packed;
+        cnt[sy] = (uint8_t)c;
         dnb[sy] = ct.dnb[sy];
         const uint32_t nb0 = (uint32_t)(ct.dnb[sy] + (1 << 15)) >> 16;
         init[sy] = (uint8_t)(ct.state[(((nb0 << 16) - (uint32_t)ct.dnb[sy]) >> nb0) + (uint32_t)ct.dfs[sy]] - size);
+        cumul += c;
     }
 }
 constexpr HdrTrans hdr_make_all_trans()
 {
     HdrTrans t{};
-    hdr_make_trans(HDR_LL_NORM, 6, t.tr + HDR_TR_LL, t.init[0], t.dnb[0]);
-    hdr_make_trans(HDR_ML_NORM, 6, t.tr + HDR_TR_ML, t.init[1], t.dnb[1]);
-    hdr_make_trans(HDR_OF_NORM, 5, t.tr + HDR_TR_OF, t.init[2], t.dnb[2]);
+    hdr_make_trans(HDR_LL_NORM, 6, t.cand[0], t.dnb[0], t.cnt[0], t.init[0]);
+    hdr_make_trans(HDR_ML_NORM, 6, t.cand[1], t.dnb[1], t.cnt[1], t.init[1]);
+    hdr_make_trans(HDR_OF_NORM, 5, t.cand[2], t.dnb[2], t.cnt[2], t.init[2]);
     return t;
 }
 __constant__ const HdrTrans c_hdr_trans = hdr_make_all_trans();
@@ -352,9 +354,9 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
         uint2 buf[HDR_CB + 1];
 #pragma unroll
         for (int j = 0; j <= (int)HDR_CB; j++) { const int idx = hi - j; buf[j] = idx >= 0 ? hseq[idx] : make_uint2(3u << 16, 0); }
-        uint32_t row[HDR_CB]; // the symbol of this lane's chain for sequence hi - j
-        uint32_t dnb[HDR_CB];
-        const uint32_t tbase = cc == 0 ? HDR_TR_LL : (cc == 1 ? HDR_TR_ML : HDR_TR_OF), tshift = cc == 2 ? 5u : 6u, tsize = 1u << tshift;
+        uint32_t cand[HDR_CB], dnb[HDR_CB], cnt[HDR_CB]; // of the symbol of this lane's chain for sequence hi - j
+        uint32_t sym0 = 0;
+        const uint32_t tsize = cc == 2 ? 32u : 64u;
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) {
             const uint2 cur = buf[j];
@@ -362,15 +364,18 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
             if (cc == 0) { const uint32_t ll = cur.x & 0xFFFFu; code = ll < 64 ? T.ll_code[ll] : (uint32_t)highbit32_d(ll) + 19; }
             else if (cc == 1) { const uint32_t mlb = (cur.x >> 16) - 3; code = mlb < 128 ? T.ml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36; }
             else code = (uint32_t)highbit32_d(hdr_ofv(cur, buf[j + 1], hi - j > 0));
-            row[j] = code;
+            if (j == 0) sym0 = code;
+            cand[j] = T.t.cand[cc][code];
             dnb[j] = (uint32_t)T.t.dnb[cc][code];
+            cnt[j] = T.t.cnt[cc][code];
         }
-        if (hi == (int)nseq - 1) st = T.t.init[cc][row[0]]; // the last sequence opens the chain: no output
+        if (hi == (int)nseq - 1) st = T.t.init[cc][sym0]; // the last sequence opens the chain: no output
         uint32_t outv[HDR_CB];
 #pragma unroll
-        for (int j = 0; j < (int)HDR_CB; j++) { // the walk: one dependent LDS read a step
+        for (int j = 0; j < (int)HDR_CB; j++) { // the walk: registers only
             const bool live = hi - j >= 0, first = hi - j == (int)nseq - 1;
-            const uint32_t nxt = T.t.tr[tbase + (row[j] << tshift) + st], nb = (st + tsize + dnb[j]) >> 16;
+            const uint32_t full = st + tsize, nb = (full + dnb[j]) >> 16, k = ((full >> nb) - cnt[j]) & 3u;
+            const uint32_t nxt = (cand[j] >> (8 * k)) & 0xFFu;
             outv[j] = first ? 0u : ((st & ((1u << nb) - 1)) | (nb << 6));
             st = (live && !first) ? nxt : st;
         }
