@@ -314,9 +314,11 @@ constexpr HdrTrans hdr_make_all_trans()
     return t;
 }
 __constant__ const HdrTrans c_hdr_trans = hdr_make_all_trans();
+// what a chain needs for one sequence in ONE 64-bit LDS read, indexed by the value itself when it is small (literal length
+// < 64, match length - 3 < 128: nearly always) and by 64 / 128 + code otherwise; offsets: by code.
+// x = the symbol's candidate next states, y = deltaNbBits | count << 24
 struct HdrChainLds {
-    HdrTrans t;
-    uint8_t ll_code[64], ml_code[128];
+    uint2 ll[64 + 36], ml[128 + 53], of[32];
 };
 __device__ __forceinline__ uint32_t hdr_ofv(const uint2 cur, const uint2 prev, bool has_prev)
 {
@@ -327,12 +329,13 @@ __device__ __forceinline__ uint32_t hdr_ofv(const uint2 cur, const uint2 prev, b
 __device__ __forceinline__ void hdr_chain_tables(HdrChainLds &T)
 {
     const uint32_t lane = threadIdx.x;
-    const uint32_t *src = (const uint32_t *)&c_hdr_trans;
-    uint32_t *dst = (uint32_t *)&T.t;
-    for (uint32_t i = lane; i < sizeof(HdrTrans) / 4; i += 64) dst[i] = src[i];
-    T.ll_code[lane] = c_hll_code[lane];
-    T.ml_code[lane] = c_hml_code[lane];
-    T.ml_code[64 + lane] = c_hml_code[64 + lane];
+    auto entry = [](int chain, uint32_t code) { return make_uint2(c_hdr_trans.cand[chain][code], (uint32_t)c_hdr_trans.dnb[chain][code] | ((uint32_t)c_hdr_trans.cnt[chain][code] << 24)); };
+    T.ll[lane] = entry(0, c_hll_code[lane]);
+    if (lane < 36) T.ll[64 + lane] = entry(0, lane);
+    T.ml[lane] = entry(1, c_hml_code[lane]);
+    T.ml[64 + lane] = entry(1, c_hml_code[64 + lane]);
+    if (lane < 53) T.ml[128 + lane] = entry(1, lane);
+    if (lane < 29) T.of[lane] = entry(2, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
@@ -354,28 +357,28 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
         uint2 buf[HDR_CB + 1];
 #pragma unroll
         for (int j = 0; j <= (int)HDR_CB; j++) { const int idx = hi - j; buf[j] = idx >= 0 ? hseq[idx] : make_uint2(3u << 16, 0); }
-        uint32_t cand[HDR_CB], dnb[HDR_CB], cnt[HDR_CB]; // of the symbol of this lane's chain for sequence hi - j
-        uint32_t sym0 = 0;
+        uint2 ent[HDR_CB]; // of the symbol of this lane's chain for sequence hi - j
         const uint32_t tsize = cc == 2 ? 32u : 64u;
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) {
             const uint2 cur = buf[j];
-            uint32_t code;
-            if (cc == 0) { const uint32_t ll = cur.x & 0xFFFFu; code = ll < 64 ? T.ll_code[ll] : (uint32_t)highbit32_d(ll) + 19; }
-            else if (cc == 1) { const uint32_t mlb = (cur.x >> 16) - 3; code = mlb < 128 ? T.ml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36; }
-            else code = (uint32_t)highbit32_d(hdr_ofv(cur, buf[j + 1], hi - j > 0));
-            if (j == 0) sym0 = code;
-            cand[j] = T.t.cand[cc][code];
-            dnb[j] = (uint32_t)T.t.dnb[cc][code];
-            cnt[j] = T.t.cnt[cc][code];
+            if (cc == 0) { const uint32_t ll = cur.x & 0xFFFFu; ent[j] = T.ll[ll < 64 ? ll : 64u + (uint32_t)highbit32_d(ll) + 19u]; }
+            else if (cc == 1) { const uint32_t mlb = (cur.x >> 16) - 3; ent[j] = T.ml[mlb < 128 ? mlb : 128u + (uint32_t)highbit32_d(mlb) + 36u]; }
+            else ent[j] = T.of[(uint32_t)highbit32_d(hdr_ofv(cur, buf[j + 1], hi - j > 0)) & 31u];
         }
-        if (hi == (int)nseq - 1) st = T.t.init[cc][sym0]; // the last sequence opens the chain: no output
+        if (hi == (int)nseq - 1) { // the last sequence opens the chain: no output
+            const uint2 cur = buf[0];
+            const uint32_t ll = cur.x & 0xFFFFu, mlb = (cur.x >> 16) - 3;
+            const uint32_t code = cc == 0 ? (ll < 64 ? c_hll_code[ll] : (uint32_t)highbit32_d(ll) + 19u)
+                                          : (cc == 1 ? (mlb < 128 ? c_hml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36u) : (uint32_t)highbit32_d(hdr_ofv(cur, buf[1], hi > 0)));
+            st = c_hdr_trans.init[cc][code];
+        }
         uint32_t outv[HDR_CB];
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) { // the walk: registers only
             const bool live = hi - j >= 0, first = hi - j == (int)nseq - 1;
-            const uint32_t full = st + tsize, nb = (full + dnb[j]) >> 16, k = ((full >> nb) - cnt[j]) & 3u;
-            const uint32_t nxt = (cand[j] >> (8 * k)) & 0xFFu;
+            const uint32_t full = st + tsize, nb = (full + (ent[j].y & 0xFFFFFFu)) >> 16, k = ((full >> nb) - ((ent[j].y >> 24) & 7u)) & 3u;
+            const uint32_t nxt = (ent[j].x >> (8 * k)) & 0xFFu;
             outv[j] = first ? 0u : ((st & ((1u << nb) - 1)) | (nb << 6));
             st = (live && !first) ? nxt : st;
         }
