@@ -1479,6 +1479,9 @@ __global__ __launch_bounds__(256) void k_dec_check(DecInfo *info, const DecBlock
 // scan of the piece totals minus its value at the record's first piece gives the sum of the pieces before;
 // a record that continues from the previous round takes the running sum carried over instead.
 // ---------------------------------------------------------------------------
+#ifndef ASM_G
+#define ASM_G 64u // records a wave assembles at a time (<= 64)
+#endif
 #define DRL(v, i) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (i)))
 #define DSH(v, i) ((uint32_t)__shfl((int)(v), (int)(i), WAVE))
 __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict__ arena, DecInfo *info, const DecBlock *__restrict__ blocks,
@@ -1488,9 +1491,9 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
     if (info->status) return;
     const uint32_t n_rec = info->n_rec, nb = info->n_blocks;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
-    const uint32_t n_groups = (n_rec + 63) >> 6;
+    const uint32_t n_groups = (n_rec + ASM_G - 1) / ASM_G;
     for (uint32_t g = wave; g < n_groups; g += nwaves) {
-        const uint32_t r = g * 64 + lane;
+        const uint32_t r = lane < ASM_G ? g * ASM_G + lane : n_rec;
         uint32_t m_L = 0, m_hdr = 0, m_H = 0, m_seq = 0, m_np = 0, m_nn = 0, m_plus = 0, m_P = 0, m_q = 0;
         size_t m_out = 0;
         if (r < n_rec) {
@@ -1904,7 +1907,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     }
     PROF(ctx, st, "k_dec_check", hipLaunchKernelGGL(k_dec_check, dim3(1), dim3(256), 0, st, info, blocks, btot, out_cap));
     if (n_rec) {
-        uint32_t g = ((n_rec + 63) / 64 + 3) / 4;
+        uint32_t g = ((n_rec + ASM_G - 1) / ASM_G + 3) / 4;
         if (g > 8192) g = 8192;
         if (!g) g = 1;
         uint32_t qoff = qual_encoding == FQZ_ENCODING_PHRED64 ? 64u : 33u;
