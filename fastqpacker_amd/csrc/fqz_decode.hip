@@ -178,10 +178,10 @@ __device__ int literals_regen(const uint8_t *p, uint32_t n, uint32_t *regen)
 // that follows (pass 2) verifies the guess and asks for the general path if a frame turns out different.
 #define FQZ_SPEC_UNKNOWN 0xFFFFFFFFu
 #define FQZ_DEC_RETRY_GENERAL (-1000) // internal: never returned to callers
-__global__ __launch_bounds__(64) void k_dec_fhdr(const uint8_t *in, DecInfo *info, DecBlock *blocks)
+__global__ __launch_bounds__(64) void k_dec_fhdr(const uint8_t *in, DecInfo *info, DecBlock *blocks, uint32_t block_cap)
 {
     const uint32_t id = blockIdx.x * 64 + threadIdx.x;
-    if (id >= info->n_blocks * FQZ_NS) return;
+    if (id >= info->n_blocks * FQZ_NS || id >= block_cap * FQZ_NS) return;
     DecBlock *b = &blocks[id / FQZ_NS];
     const int s = id % FQZ_NS;
     const uint32_t n = b->pay_len[s];
@@ -1735,31 +1735,60 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     d.d_in = d_in; d.n_bytes = n_bytes; d.stream = st;
     d.version = version; d.qual_encoding = qual_encoding; d.user_out = d_out; d.user_cap = out_cap; d.general = general;
 
-    // ---- pass A: count blocks
-    HIP_TRY(hipMemsetAsync(info, 0, sizeof(DecInfo), st));
-    PROF(ctx, st, "k_dec_blocks", hipLaunchKernelGGL(k_dec_blocks, dim3(1), dim3(64), 0, st, d_in, n, (uint32_t)version, info, (DecBlock *)nullptr, 0u));
-    HIP_TRY(hipMemcpyAsync(hi, info, sizeof(DecInfo), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (hi->status) return hi->status;
-    const uint32_t nb = hi->n_blocks, n_rec = hi->n_rec;
+    // ---- block table and payload sizes.  Our own payloads (and any payload whose first frame states its size) need no walk
+    //      for that, so the table is filled optimistically for up to cap0 blocks in ONE pass (one read-back instead of two);
+    //      a container with more blocks, and the general path, count the blocks first.
+    uint32_t nb = 0, n_rec = 0, fgrid = 0;
+    DecBlock *blocks = nullptr;
+    bool have_table = false;
+    if (!general) {
+        const uint32_t cap0 = 4096;
+        if ((rc = d.blocks.ensure(sizeof(DecBlock) * (size_t)cap0))) return rc;
+        if ((rc = d.h_blocks.ensure(sizeof(DecBlock) * (size_t)cap0))) return rc;
+        blocks = d.blocks.as<DecBlock>();
+        HIP_TRY(hipMemsetAsync(info, 0, sizeof(DecInfo), st));
+        HIP_TRY(hipMemsetAsync(blocks, 0, sizeof(DecBlock) * (size_t)cap0, st));
+        PROF(ctx, st, "k_dec_blocks", hipLaunchKernelGGL(k_dec_blocks, dim3(1), dim3(64), 0, st, d_in, n, (uint32_t)version, info, blocks, cap0));
+        PROF(ctx, st, "k_dec_fhdr", hipLaunchKernelGGL(k_dec_fhdr, dim3((cap0 * FQZ_NS + 63) / 64), dim3(64), 0, st, d_in, info, blocks, cap0));
+        HIP_TRY(hipMemcpyAsync(hi, info, sizeof(DecInfo), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (hi->status) return hi->status;
+        nb = hi->n_blocks; n_rec = hi->n_rec;
+        if (nb && nb <= cap0) {
+            HIP_TRY(hipMemcpyAsync(d.h_blocks.p, blocks, sizeof(DecBlock) * (size_t)nb, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            have_table = true;
+        }
+    } else {
+        // ---- pass A: count blocks
+        HIP_TRY(hipMemsetAsync(info, 0, sizeof(DecInfo), st));
+        PROF(ctx, st, "k_dec_blocks", hipLaunchKernelGGL(k_dec_blocks, dim3(1), dim3(64), 0, st, d_in, n, (uint32_t)version, info, (DecBlock *)nullptr, 0u));
+        HIP_TRY(hipMemcpyAsync(hi, info, sizeof(DecInfo), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (hi->status) return hi->status;
+        nb = hi->n_blocks; n_rec = hi->n_rec;
+    }
     d.n_blocks = nb;
     if (!nb) { // empty container body (compress.go:591-593)
         memset(hi, 0, sizeof *hi);
         d.d_out = d_out; d.out_cap = out_cap; d.in_flight = true;
         return FQZ_OK;
     }
-    // ---- pass B: block table + frame walk (sizes)
-    if ((rc = d.blocks.ensure(sizeof(DecBlock) * (size_t)nb))) return rc;
-    if ((rc = d.h_blocks.ensure(sizeof(DecBlock) * (size_t)nb))) return rc;
-    DecBlock *blocks = d.blocks.as<DecBlock>();
-    HIP_TRY(hipMemsetAsync(blocks, 0, sizeof(DecBlock) * (size_t)nb, st));
-    PROF(ctx, st, "k_dec_blocks", hipLaunchKernelGGL(k_dec_blocks, dim3(1), dim3(64), 0, st, d_in, n, (uint32_t)version, info, blocks, nb));
-    uint32_t fgrid = nb * FQZ_NS; // one wave per (block, stream)
-    if (general) PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, (DecChunk *)nullptr, (DecFrame *)nullptr, 0));
-    else PROF(ctx, st, "k_dec_fhdr", hipLaunchKernelGGL(k_dec_fhdr, dim3((fgrid + 63) / 64), dim3(64), 0, st, d_in, info, blocks));
-    HIP_TRY(hipMemcpyAsync(hi, info, sizeof(DecInfo), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(d.h_blocks.p, blocks, sizeof(DecBlock) * (size_t)nb, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    fgrid = nb * FQZ_NS; // one wave per (block, stream)
+    if (!have_table) {
+        // ---- pass B: block table + frame walk (sizes)
+        if ((rc = d.blocks.ensure(sizeof(DecBlock) * (size_t)nb))) return rc;
+        if ((rc = d.h_blocks.ensure(sizeof(DecBlock) * (size_t)nb))) return rc;
+        blocks = d.blocks.as<DecBlock>();
+        HIP_TRY(hipMemsetAsync(info, 0, sizeof(DecInfo), st));
+        HIP_TRY(hipMemsetAsync(blocks, 0, sizeof(DecBlock) * (size_t)nb, st));
+        PROF(ctx, st, "k_dec_blocks", hipLaunchKernelGGL(k_dec_blocks, dim3(1), dim3(64), 0, st, d_in, n, (uint32_t)version, info, blocks, nb));
+        if (general) PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, (DecChunk *)nullptr, (DecFrame *)nullptr, 0));
+        else PROF(ctx, st, "k_dec_fhdr", hipLaunchKernelGGL(k_dec_fhdr, dim3((fgrid + 63) / 64), dim3(64), 0, st, d_in, info, blocks, nb));
+        HIP_TRY(hipMemcpyAsync(hi, info, sizeof(DecInfo), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(d.h_blocks.p, blocks, sizeof(DecBlock) * (size_t)nb, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     if (hi->status) return hi->status;
     if (!general) { // a payload whose frame header does not tell its size: take the two-walk path
         const DecBlock *hb0 = d.h_blocks.as<DecBlock>();
