@@ -41,6 +41,8 @@ def _hdr_cases():
     yield "tail only", _records([bytes(rng.integers(65, 91, 12, dtype=np.uint8)) + b" common tail of some length" for _ in range(3000)])
     yield "very long headers (offsets beyond the decoder's ring)", _records([b"%07d|" % i + bytes(rng.integers(65, 91, 600, dtype=np.uint8)) * (0 if i % 5 else 1) + b"GATTACA" * 700 for i in range(60)])
     yield "long runs of one byte (overlapping matches)", _records([b"N" * int(n) for n in rng.integers(1500, 3000, 60)])
+    yield "mostly headers, 3 MB (more headers chunks than the encoder's side buffers expect: it relaunches)", _records(
+        [b"run7:lane%d:tile%d:" % (i % 8, i // 97) + bytes(rng.integers(97, 123, 900, dtype=np.uint8)) + b":%d" % i for i in range(3300)], L=8)
     yield "crlf", make_fastq(800, seed=32, crlf=True)
 
 
