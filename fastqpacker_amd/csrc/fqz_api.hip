@@ -199,7 +199,7 @@ extern "C" size_t fqz_encode_bound_blocks(size_t n_bytes, uint32_t rpb)
     // payloads with a 24-byte index, a short last group and a short last chunk each
     if (!rpb) rpb = FQZ_DEFAULT_BLOCK_SIZE;
     const size_t blocks = n_bytes / 6 / rpb + 2;
-    return 2 * n_bytes + (n_bytes / 1024 + 64) * 128 + blocks * (36 + 6 * (24 + 11 + 6)) + 4096;
+    return 2 * n_bytes + (n_bytes / 1024 + 64) * 128 + blocks * (36 + 6 * (24 + 11 + 6) + 3 * 4) + n_bytes / 32 /* record samples: 12 bytes per 64 records */ + 4096;
 }
 extern "C" size_t fqz_encode_bound(size_t n_bytes) { return fqz_encode_bound_blocks(n_bytes, FQZ_DEFAULT_BLOCK_SIZE); }
 

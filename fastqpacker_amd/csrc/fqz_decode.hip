@@ -33,6 +33,7 @@ struct DecBlock {
     uint32_t indexed[FQZ_NS];       // the payload starts with our index frame (FQZ-H2): its zstd blocks are located without a walk
     uint32_t n_frames[FQZ_NS];      // zstd frames of the payload (content checksums are verified per frame)
     uint32_t frame_base[FQZ_NS];    // first entry of the payload in the frame table
+    uint32_t samp_off[FQZ_NS];      // offset in d_in of the record samples of the payload's index (stream offsets of records 64, 128, ...); 0: none
     uint32_t seq_scratch;           // arena offset of the scratch of the headers stream's blocks with sequences (DSEQ_STRIDE each; 0: none)
 };
 
@@ -141,13 +142,25 @@ __device__ int frame_header(const uint8_t *p, uint32_t n, uint32_t *hdr, long lo
 __device__ __forceinline__ bool skippable_magic(const uint8_t *p) { return (p[0] & 0xF0) == 0x50 && p[1] == 0x2A && p[2] == 0x4D && p[3] == 0x18; }
 // FQZ-H2 index in front of a payload: 'FQZI', version 1, stream, pre-entropy length, zstd block count, 3 bytes per block
 #define H2_IDX_HDR 24u
-__device__ __forceinline__ bool h2_index(const uint8_t *p, uint32_t n, uint32_t *raw, uint32_t *nch)
+// flags bit 0: behind the block sizes, [records u32][stream offset u32 of records 64, 128, ...] (*samples = offset of the first
+// one inside the payload, *srec = the record count it was made for)
+__device__ __forceinline__ bool h2_index(const uint8_t *p, uint32_t n, uint32_t *raw, uint32_t *nch, uint32_t *samples, uint32_t *srec)
 {
     if (n < H2_IDX_HDR || !skippable_magic(p) || p[0] != 0x50) return false;
     if (!(p[8] == 'F' && p[9] == 'Q' && p[10] == 'Z' && p[11] == 'I' && p[12] == 1)) return false;
-    const uint32_t sz = rd32(p + 4), r = rd32(p + 16), c = rd32(p + 20);
-    if (r == 0 || r > 0x7FFFFFF0u || c != (r + FQZ_CHUNK - 1) / FQZ_CHUNK) return false;
-    if (sz != H2_IDX_HDR - 8 + 3ull * c || 8ull + sz > n) return false;
+    const uint32_t sz = rd32(p + 4), r = rd32(p + 16), c = rd32(p + 20), flags = p[14] | ((uint32_t)p[15] << 8);
+    if (r == 0 || r > 0x7FFFFFF0u || c != (r + FQZ_CHUNK - 1) / FQZ_CHUNK || (flags & ~1u)) return false;
+    unsigned long long want = H2_IDX_HDR - 8 + 3ull * c;
+    *samples = 0; *srec = 0;
+    if (flags & 1) {
+        if (8ull + want + 4 > n) return false;
+        const uint32_t nr = rd32(p + H2_IDX_HDR + 3 * c);
+        if (nr <= 64) return false;
+        want += 4 + 4ull * ((nr - 1) / 64);
+        *samples = H2_IDX_HDR + 3 * c + 4;
+        *srec = nr;
+    }
+    if (sz != want || 8ull + sz > n) return false;
     *raw = r;
     *nch = c;
     return true;
@@ -186,13 +199,15 @@ __global__ __launch_bounds__(64) void k_dec_fhdr(const uint8_t *in, DecInfo *inf
     const int s = id % FQZ_NS;
     const uint32_t n = b->pay_len[s];
     b->indexed[s] = 0;
+    b->samp_off[s] = 0;
     if (!n) { b->raw_len[s] = 0; b->n_chunks[s] = 0; b->n_frames[s] = 0; return; }
-    uint32_t raw, nch;
-    if (h2_index(in + b->pay_off[s], n, &raw, &nch)) { // our own payload: sizes and block places come from its index (k_dec_index)
+    uint32_t raw, nch, samples, srec;
+    if (h2_index(in + b->pay_off[s], n, &raw, &nch, &samples, &srec)) { // our own payload: sizes and block places come from its index (k_dec_index)
         b->raw_len[s] = raw;
         b->n_chunks[s] = nch;
         b->n_frames[s] = (nch + FQZ_GROUP - 1) / FQZ_GROUP;
         b->indexed[s] = 1;
+        if (samples && srec == b->nrec && (s == S_HDR || s == S_PLUS || s == S_NPOS)) b->samp_off[s] = b->pay_off[s] + samples;
         return;
     }
     uint32_t hdr;
@@ -683,7 +698,7 @@ __global__ __launch_bounds__(256) void k_dec_index(const uint8_t *in, DecInfo *i
     const uint8_t *idx = in + p0 + H2_IDX_HDR;
     DecChunk *out = chunks + b->chunk_base[s];
     DecFrame *fout = frames + b->frame_base[s];
-    const uint32_t body0 = p0 + H2_IDX_HDR + 3 * nch; // first byte behind the index
+    const uint32_t body0 = p0 + 8 + rd32(in + p0 + 4); // first byte behind the index frame
     uint32_t carry = 0;
     bool bad = false;
     for (uint32_t c0 = 0; c0 < nch; c0 += 256) {
@@ -1189,7 +1204,36 @@ __global__ __launch_bounds__(1024) void k_dec_walk0(const uint8_t *arena, DecInf
         }
         if (!__syncthreads_or(bad != 0)) { for (uint32_t r = t; r < nrec; r += 1024) out[r] = 2 * r; mode = 1; }
     } else if (nrec == 0) mode = 1;
+    if (mode == 0 && b->samp_off[s]) mode = 2; // the index carries record samples: k_dec_walk_s
     if (t == 0) b->walk_mode[which] = mode;
+}
+
+// Streams whose index carries record samples (the stream offset of every 64th record): a lane walks the 64 records behind its
+// sample and must arrive exactly at the next one (the index is a hint: anything that does not add up sends the batch to the
+// general path, which walks the chains from the start and names the error).  grid: (ceil(groups / 64), blocks x 3)
+__global__ __launch_bounds__(64) void k_dec_walk_s(const uint8_t *in, const uint8_t *arena, DecInfo *info, const DecBlock *blocks, uint32_t *offs, uint32_t ostride)
+{
+    const uint32_t bidx = blockIdx.y / 3, which = blockIdx.y % 3;
+    if (bidx >= info->n_blocks || info->status) return;
+    const DecBlock *b = &blocks[bidx];
+    if (b->walk_mode[which] != 2) return;
+    const int s = walk_stream((int)which);
+    const uint32_t unit = s == S_NPOS ? 2 : 1, len = b->raw_len[s], nrec = b->nrec, ngroups = (nrec + 63) / 64;
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint8_t *samp = in + b->samp_off[s]; // sample k (record 64 k, k >= 1) at 4 (k - 1)
+    uint32_t pos = g ? rd32(samp + 4 * (g - 1)) : 0u;
+    const uint32_t want = g + 1 < ngroups ? rd32(samp + 4 * g) : len;
+    const uint8_t *p = arena + b->a_off[s];
+    uint32_t *out = offs + (size_t)which * ostride + b->rec_base + 64 * g;
+    const uint32_t cnt = nrec - 64 * g < 64 ? nrec - 64 * g : 64;
+    bool bad = pos > len || want > len;
+    for (uint32_t i = 0; i < cnt && !bad; i++) {
+        if (pos + 2 > len) { bad = true; break; }
+        out[i] = pos;
+        pos += 2 + unit * rd16(p + pos);
+    }
+    if (bad || pos != want) dec_fail(info, FQZ_DEC_RETRY_GENERAL);
 }
 
 // tile -> (block, which, first byte of the tile in the stream)
@@ -1809,7 +1853,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             chunks += hb[b].n_chunks[s];
             hb[b].frame_base[s] = (uint32_t)nframes;
             nframes += hb[b].n_frames[s];
-            if (general) hb[b].indexed[s] = 0; // the general path walks every payload, index or not
+            if (general) { hb[b].indexed[s] = 0; hb[b].samp_off[s] = 0; } // the general path walks every payload and every chain, index or not
             any_indexed |= hb[b].indexed[s] != 0;
             if (hb[b].lz[s]) hb[b].lz[s] = (uint32_t)++n_lz; // 1 + scratch slot
             hi->stream_raw[s] += hb[b].raw_len[s];
@@ -1823,6 +1867,10 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         }
         out_bound += (unsigned long long)hb[b].raw_len[S_HDR] + hb[b].raw_len[S_PLUS] + 2ull * hb[b].raw_len[S_QUAL] + 4ull * hb[b].nrec;
     }
+    uint32_t max_sgroups = 0; // groups of 64 records of the largest block whose index carries record samples
+    for (uint32_t b = 0; b < nb; b++)
+        for (int s = 0; s < FQZ_NS; s++)
+            if (hb[b].samp_off[s] && (hb[b].nrec + 63) / 64 > max_sgroups) max_sgroups = (hb[b].nrec + 63) / 64;
     bool any_seq = false; // scratch for the blocks with sequences of our own headers streams (fqz_decode_seq.h), behind the streams
     for (uint32_t b = 0; b < nb; b++) {
         hb[b].seq_scratch = 0;
@@ -1917,6 +1965,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     }
     if (n_lz) PROF(ctx, st, "k_dec_lz", hipLaunchKernelGGL(k_dec_lz, dim3(fgrid), dim3(64), 0, st, d_in, info, blocks, darena, d.lz_scratch.as<uint8_t>()));
     PROF(ctx, st, "k_dec_walk0", hipLaunchKernelGGL(k_dec_walk0, dim3(nb * 3), dim3(1024), 0, st, darena, info, blocks, offs, ostride));
+    if (max_sgroups) PROF(ctx, st, "k_dec_walk_s", hipLaunchKernelGGL(k_dec_walk_s, dim3((max_sgroups + 63) / 64, nb * 3), dim3(64), 0, st, d_in, darena, info, blocks, offs, ostride));
     if (n_tiles) {
         PROF(ctx, st, "k_dec_walk1", hipLaunchKernelGGL(k_dec_walk1, dim3(n_tiles), dim3(256), 0, st, darena, info, blocks, n_tiles, walkF));
         PROF(ctx, st, "k_dec_walk2", hipLaunchKernelGGL(k_dec_walk2, dim3(nb * 3), dim3(64), 0, st, darena, info, blocks, walkF, walkE));

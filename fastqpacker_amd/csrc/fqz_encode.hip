@@ -826,7 +826,13 @@ __device__ __forceinline__ void locate_chunk(const EncInfo *info, const BlockPla
 
 // FQZ-H2 payload geometry of a stream of len bytes (nch chunks, ng groups): [24-byte index header | 3 bytes per chunk |
 // per group: frame header (6 bytes when the group holds < 256 bytes, else 7), its zstd blocks, 4-byte checksum]
-__device__ __forceinline__ uint32_t h2_idx_len(uint32_t nch) { return 24u + 3u * nch; }
+// record samples (the stream offset of every 64th record of the headers / plus / nPos streams): how many a stream of len
+// bytes and nrec records carries (none when every record is a bare prefix: offset = 2 x record)
+__device__ __forceinline__ uint32_t h2_samples(int s, uint32_t len, uint32_t nrec)
+{
+    return ((s == S_HDR || s == S_PLUS || s == S_NPOS) && nrec > 64 && len != 2 * nrec) ? (nrec - 1) / 64 : 0u;
+}
+__device__ __forceinline__ uint32_t h2_idx_len(uint32_t nch, uint32_t ns) { return 24u + 3u * nch + (ns ? 4u + 4u * ns : 0u); }
 __device__ __forceinline__ uint32_t h2_group_bytes(uint32_t len, uint32_t g) { const uint32_t off = g * FQZ_GROUP * FQZ_CHUNK; return len - off < FQZ_GROUP * FQZ_CHUNK ? len - off : FQZ_GROUP * FQZ_CHUNK; }
 __device__ __forceinline__ uint32_t h2_frame_hdr(uint32_t M) { return M < 256u ? 6u : 7u; }
 
@@ -1072,7 +1078,7 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
             for (int s = 0; s < FQZ_NS; s++) {
                 const uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK, ng = (nch + FQZ_GROUP - 1) / FQZ_GROUP;
                 // index frame + per group (frame header + checksum) + the zstd blocks
-                flen[s] = nch ? h2_idx_len(nch) + 11u * (ng - 1) + h2_frame_hdr(h2_group_bytes(p->len[s], ng - 1)) + 4u +
+                flen[s] = nch ? h2_idx_len(nch, h2_samples(s, p->len[s], p->nrec)) + 11u * (ng - 1) + h2_frame_hdr(h2_group_bytes(p->len[s], ng - 1)) + 4u +
                                     (cpre[p->chunk_base[s] + nch] - cpre[p->chunk_base[s]]) : 0;
                 size += flen[s];
             }
@@ -1116,16 +1122,32 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
         for (int s = 0; s < FQZ_NS; s++) {
             if (!p->frame_len[s]) continue;
             // the index: a zstd skippable frame in front of the payload's frames (k_compact fills in the block sizes)
-            const uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
+            const uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK, ns = h2_samples(s, p->len[s], p->nrec);
             uint8_t *f = out + p->frame_off[s];
             put_le32(f, 0x184D2A50u);
-            put_le32(f + 4, h2_idx_len(nch) - 8);
+            put_le32(f + 4, h2_idx_len(nch, ns) - 8);
             f[8] = 'F'; f[9] = 'Q'; f[10] = 'Z'; f[11] = 'I';
-            f[12] = 1; f[13] = (uint8_t)s; f[14] = 0; f[15] = 0;
+            f[12] = 1; f[13] = (uint8_t)s; f[14] = ns ? 1 : 0; f[15] = 0; // flags: bit 0 = record samples behind the block sizes
             put_le32(f + 16, p->len[s]);
             put_le32(f + 20, nch);
+            if (ns) put_le32(f + 24 + 3 * nch, p->nrec); // (k_samples writes the offsets)
         }
     }
+}
+
+// The record samples of the index frames: thread k of (block, stream) writes the stream offset of record 64 (k + 1).
+// grid: (ceil(max samples / 256), blocks x 3)
+__global__ __launch_bounds__(256) void k_samples(const EncInfo *info, const BlockPlan *plans, const uint32_t *E, uint32_t estride, uint8_t *out)
+{
+    const uint32_t b = blockIdx.y / 3, w = blockIdx.y % 3;
+    if (info->status || b >= info->n_blocks) return;
+    const BlockPlan *p = &plans[b];
+    const int s = w == 0 ? S_HDR : (w == 1 ? S_PLUS : S_NPOS);
+    const uint32_t ns = h2_samples(s, p->len[s], p->nrec), k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns) return;
+    const uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
+    const uint32_t *Es = E + (size_t)s * estride;
+    put_le32(out + p->frame_off[s] + 24 + 3 * nch + 4 + 4 * k, Es[p->rec0 + 64 * (k + 1)] - Es[p->rec0]);
 }
 
 // One workgroup per chunk: its zstd block -> its place in its frame (any alignment), plus what frames the block: the
@@ -1147,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const Bloc
     const uint32_t nch = (len + FQZ_CHUNK - 1) / FQZ_CHUNK, g = c / FQZ_GROUP;
     const uint32_t M = h2_group_bytes(len, g), fh = h2_frame_hdr(M);
     uint8_t *const pay = out + p->frame_off[s];
-    uint8_t *dst = pay + h2_idx_len(nch) + 11u * g + fh + (c0 - cpre[base]);
+    uint8_t *dst = pay + h2_idx_len(nch, h2_samples((int)s, len, p->nrec)) + 11u * g + fh + (c0 - cpre[base]);
     uint32_t n = c1 - c0;
     const bool first_in_group = c % FQZ_GROUP == 0, last_in_group = c % FQZ_GROUP == FQZ_GROUP - 1 || c + 1 == nch;
     if (t == 0) {
@@ -1373,6 +1395,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, st, "k_hdr_patch", hipLaunchKernelGGL(k_hdr_patch, dim3(hcap), dim3(64), 0, st, info, hlist, hcap, hside, hsec, slots, csize));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap, hcap));
+    PROF(ctx, st, "k_samples", hipLaunchKernelGGL(k_samples, dim3((rpb / 64 + 255) / 256, e.block_cap * 3), dim3(256), 0, st, info, plans, E, estride, d_out));
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, xsum, arena, d_out, (uint32_t)S_SEQ));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));

@@ -690,31 +690,43 @@ size_t fqzo_entropy_bound(size_t n)
 {
     if (!n) return 0;
     const size_t chunks = (n + FQZO_CHUNK - 1) / FQZO_CHUNK, groups = (chunks + FQZO_GROUP - 1) / FQZO_GROUP;
-    return FQZO_IDX_HDR + 3 * chunks + groups * (7 + 4) + n + 3 * chunks;
+    return FQZO_IDX_HDR + 3 * chunks + (4 + 4 * (n / 128 + 1)) /* record samples: a record is >= 2 bytes */ + groups * (7 + 4) + n + 3 * chunks;
 }
 
 size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint8_t *dst)
 {
     if (!n) return 0;
     const size_t chunks = (n + FQZO_CHUNK - 1) / FQZO_CHUNK;
-    uint8_t *idx = dst, *op = dst + FQZO_IDX_HDR + 3 * chunks;
+    /* headers / plus / nPos streams are chains of length-prefixed records ([u16 k][k units]; compress.go:507-517): their
+     * record starts (a walk over the prefixes); anything that is not a clean chain of records has none */
+    uint32_t *rs = NULL, nr = 0;
+    if (stream == 2 || stream == 3 || stream == 4) {
+        const size_t unit = stream == 4 ? 2 : 1;
+        rs = (uint32_t *)malloc(sizeof(uint32_t) * (n / 2 + 2));
+        size_t pos = 0;
+        while (pos + 2 <= n) { rs[nr++] = (uint32_t)pos; pos += 2 + unit * (size_t)(src[pos] | (src[pos + 1] << 8)); }
+        if (pos != n) { free(rs); rs = NULL; nr = 0; } else rs[nr] = (uint32_t)n;
+    }
+    /* record samples: the stream offset of every 64th record (64, 128, ...), so that a parallel decoder finds the records
+     * without walking the chain from the start (it checks them against the walk it does between two samples).  Not for
+     * streams whose records are all bare prefixes (offset = 2 x record) */
+    const uint32_t ns = (rs && nr > 64 && n != 2 * (size_t)nr) ? (nr - 1) / 64 : 0;
+    const size_t idx_len = FQZO_IDX_HDR + 3 * chunks + (ns ? 4 + 4 * (size_t)ns : 0);
+    uint8_t *idx = dst, *op = dst + idx_len;
     put32le(idx, 0x184D2A50u);
-    put32le(idx + 4, (uint32_t)(FQZO_IDX_HDR - 8 + 3 * chunks));
+    put32le(idx + 4, (uint32_t)(idx_len - 8));
     idx[8] = 'F'; idx[9] = 'Q'; idx[10] = 'Z'; idx[11] = 'I';
-    idx[12] = 1; idx[13] = (uint8_t)stream; idx[14] = 0; idx[15] = 0;
+    idx[12] = 1; idx[13] = (uint8_t)stream; idx[14] = ns ? 1 : 0; idx[15] = 0; /* flags: bit 0 = record samples present */
     put32le(idx + 16, (uint32_t)n);
     put32le(idx + 20, (uint32_t)chunks);
     uint8_t *ent = idx + FQZO_IDX_HDR;
-    const size_t G = (size_t)FQZO_GROUP * FQZO_CHUNK;
-    /* headers stream: the record starts (a walk over the u16 length prefixes); anything that is not a clean chain of
-     * records is coded without matches */
-    uint32_t *rs = NULL, nr = 0;
-    if (stream == 2) {
-        rs = (uint32_t *)malloc(sizeof(uint32_t) * (n / 2 + 2));
-        size_t pos = 0;
-        while (pos + 2 <= n) { rs[nr++] = (uint32_t)pos; pos += 2 + (size_t)(src[pos] | (src[pos + 1] << 8)); }
-        if (pos != n) { free(rs); rs = NULL; nr = 0; } else rs[nr] = (uint32_t)n;
+    if (ns) {
+        uint8_t *sp = idx + FQZO_IDX_HDR + 3 * chunks;
+        put32le(sp, nr);
+        for (uint32_t k = 1; k <= ns; k++) put32le(sp + 4 * k, rs[64 * k]);
     }
+    const size_t G = (size_t)FQZO_GROUP * FQZO_CHUNK;
+    if (stream != 2) { free(rs); rs = NULL; } /* (only the headers are modelled) */
     hseq *sqbuf = rs ? (hseq *)malloc(sizeof(hseq) * FQZO_GROUP * HDR_MAX_SEQ) : NULL;
     uint8_t *litbuf = rs ? (uint8_t *)malloc(G) : NULL;
     for (size_t off = 0; off < n; off += G) {

@@ -120,3 +120,34 @@ def test_gpu_rejects_damaged_sequences(fq):
             continue
         assert out == text                     # (a flip in padding bits of a bitstream can be harmless)
     assert n_fail >= 20
+
+
+@pytest.mark.gpu
+def test_record_samples_are_a_hint(fq):
+    """The index frame of the headers payload carries the stream offset of every 64th record.  A wrong sample must not
+    change the result: the decoder checks every sample against the walk between its neighbours and falls back to walking
+    the chain from the start."""
+    text = make_fastq(1000, seed=35, min_len=30, max_len=60)
+    good = fq.compress.Compress(text)
+    assert good == O.compress(text)
+    hdr = [int.from_bytes(good[10 + 4 * i: 14 + 4 * i], "little") for i in range(9)]
+    h_off = 10 + 36 + hdr[1] + hdr[2]
+    pay = good[h_off: h_off + hdr[3]]
+    assert pay[8:12] == b"FQZI" and pay[14] == 1                      # flags: samples present
+    nch = int.from_bytes(pay[20:24], "little")
+    at = 24 + 3 * nch
+    assert int.from_bytes(pay[at:at + 4], "little") == 1000             # the record count they were made for
+    n_s = (1000 - 1) // 64
+    samples = [int.from_bytes(pay[at + 4 + 4 * k: at + 8 + 4 * k], "little") for k in range(n_s)]
+    recs, n = O.parse_all(text)
+    h = O.split_block(text, recs, n, 0)[0][2]
+    pos, starts = 0, []
+    while pos < len(h):
+        starts.append(pos)
+        pos += 2 + int.from_bytes(h[pos:pos + 2], "little")
+    assert samples == [starts[64 * (k + 1)] for k in range(n_s)]
+    assert fq.compress.Decompress(good) == text
+    for k in (0, 7, n_s - 1):
+        bad = bytearray(good)
+        bad[h_off + at + 4 + 4 * k] ^= 0x10
+        assert fq.compress.Decompress(bytes(bad)) == text
