@@ -1210,16 +1210,16 @@ __global__ __launch_bounds__(1024) void k_dec_walk0(const uint8_t *arena, DecInf
 
 // Streams whose index carries record samples (the stream offset of every 64th record): a lane walks the 64 records behind its
 // sample and must arrive exactly at the next one (the index is a hint: anything that does not add up sends the batch to the
-// general path, which walks the chains from the start and names the error).  grid: (ceil(groups / 64), blocks x 3)
-__global__ __launch_bounds__(64) void k_dec_walk_s(const uint8_t *in, const uint8_t *arena, DecInfo *info, const DecBlock *blocks, uint32_t *offs, uint32_t ostride)
+// general path, which walks the chains from the start and names the error).  grid: xper workgroups per (block, stream)
+__global__ __launch_bounds__(64) void k_dec_walk_s(const uint8_t *in, const uint8_t *arena, DecInfo *info, const DecBlock *blocks, uint32_t *offs, uint32_t ostride, uint32_t xper)
 {
-    const uint32_t bidx = blockIdx.y / 3, which = blockIdx.y % 3;
+    const uint32_t bw = blockIdx.x / xper, bx = blockIdx.x % xper, bidx = bw / 3, which = bw % 3;
     if (bidx >= info->n_blocks || info->status) return;
     const DecBlock *b = &blocks[bidx];
     if (b->walk_mode[which] != 2) return;
     const int s = walk_stream((int)which);
     const uint32_t unit = s == S_NPOS ? 2 : 1, len = b->raw_len[s], nrec = b->nrec, ngroups = (nrec + 63) / 64;
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t g = bx * 64 + threadIdx.x;
     if (g >= ngroups) return;
     const uint8_t *samp = in + b->samp_off[s]; // sample k (record 64 k, k >= 1) at 4 (k - 1)
     uint32_t pos = g ? rd32(samp + 4 * (g - 1)) : 0u;
@@ -1965,7 +1965,10 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     }
     if (n_lz) PROF(ctx, st, "k_dec_lz", hipLaunchKernelGGL(k_dec_lz, dim3(fgrid), dim3(64), 0, st, d_in, info, blocks, darena, d.lz_scratch.as<uint8_t>()));
     PROF(ctx, st, "k_dec_walk0", hipLaunchKernelGGL(k_dec_walk0, dim3(nb * 3), dim3(1024), 0, st, darena, info, blocks, offs, ostride));
-    if (max_sgroups) PROF(ctx, st, "k_dec_walk_s", hipLaunchKernelGGL(k_dec_walk_s, dim3((max_sgroups + 63) / 64, nb * 3), dim3(64), 0, st, d_in, darena, info, blocks, offs, ostride));
+    if (max_sgroups) {
+        const uint32_t xper = (max_sgroups + 63) / 64;
+        PROF(ctx, st, "k_dec_walk_s", hipLaunchKernelGGL(k_dec_walk_s, dim3(xper * nb * 3), dim3(64), 0, st, d_in, darena, info, blocks, offs, ostride, xper));
+    }
     if (n_tiles) {
         PROF(ctx, st, "k_dec_walk1", hipLaunchKernelGGL(k_dec_walk1, dim3(n_tiles), dim3(256), 0, st, darena, info, blocks, n_tiles, walkF));
         PROF(ctx, st, "k_dec_walk2", hipLaunchKernelGGL(k_dec_walk2, dim3(nb * 3), dim3(64), 0, st, darena, info, blocks, walkF, walkE));

@@ -1136,14 +1136,14 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
 }
 
 // The record samples of the index frames: thread k of (block, stream) writes the stream offset of record 64 (k + 1).
-// grid: (ceil(max samples / 256), blocks x 3)
-__global__ __launch_bounds__(256) void k_samples(const EncInfo *info, const BlockPlan *plans, const uint32_t *E, uint32_t estride, uint8_t *out)
+// grid: xper workgroups per (block, stream), xper = ceil(max samples / 256)
+__global__ __launch_bounds__(256) void k_samples(const EncInfo *info, const BlockPlan *plans, const uint32_t *E, uint32_t estride, uint8_t *out, uint32_t xper)
 {
-    const uint32_t b = blockIdx.y / 3, w = blockIdx.y % 3;
+    const uint32_t bw = blockIdx.x / xper, bx = blockIdx.x % xper, b = bw / 3, w = bw % 3;
     if (info->status || b >= info->n_blocks) return;
     const BlockPlan *p = &plans[b];
     const int s = w == 0 ? S_HDR : (w == 1 ? S_PLUS : S_NPOS);
-    const uint32_t ns = h2_samples(s, p->len[s], p->nrec), k = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t ns = h2_samples(s, p->len[s], p->nrec), k = bx * 256 + threadIdx.x;
     if (k >= ns) return;
     const uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
     const uint32_t *Es = E + (size_t)s * estride;
@@ -1395,7 +1395,10 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, st, "k_hdr_patch", hipLaunchKernelGGL(k_hdr_patch, dim3(hcap), dim3(64), 0, st, info, hlist, hcap, hside, hsec, slots, csize));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap, hcap));
-    PROF(ctx, st, "k_samples", hipLaunchKernelGGL(k_samples, dim3((rpb / 64 + 255) / 256, e.block_cap * 3), dim3(256), 0, st, info, plans, E, estride, d_out));
+    if (rpb > 64) { // (blocks of <= 64 records carry no samples)
+        const uint32_t xper = (rpb / 64 + 255) / 256;
+        PROF(ctx, st, "k_samples", hipLaunchKernelGGL(k_samples, dim3(xper * e.block_cap * 3), dim3(256), 0, st, info, plans, E, estride, d_out, xper));
+    }
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, xsum, arena, d_out, (uint32_t)S_SEQ));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
