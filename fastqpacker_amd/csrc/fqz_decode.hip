@@ -1937,6 +1937,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             HIP_TRY(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
             HIP_TRY(hipStreamCreateWithFlags(&d.side2, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&d.ev_join2, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&d.ev_x, hipEventDisableTiming));
         }
         static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: one stream (standalone kernel times)
         const hipStream_t sd = dbg_serial ? st : d.side;
@@ -1956,9 +1957,12 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         }
         PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late));
         PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, sd, d_in, info, dch, darena, late));
-        if (n_frames) { // content checksums of the decoded frames: beside the walks / on the side stream, like the decodes they check
-            PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, st, d_in, info, dfr, n_frames, darena, early));
+        if (n_frames) { // content checksums of the decoded frames, all on the side stream: nothing on the caller's stream needs them
+            // before the text is assembled (the early streams are complete once the sequences have been executed: ev_x)
+            HIP_TRY(hipEventRecord(d.ev_x, st));
             PROF(ctx, sd, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, sd, d_in, info, dfr, n_frames, darena, late));
+            HIP_TRY(hipStreamWaitEvent(d.side, d.ev_x, 0));
+            PROF(ctx, sd, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, sd, d_in, info, dfr, n_frames, darena, early));
         }
         HIP_TRY(hipEventRecord(d.ev_join, d.side));
         forked = true;
