@@ -85,6 +85,7 @@ struct EncState {
     DevBuf gmap;      // chunk-group descriptors (k_group_map)
     DevBuf hside;     // headers model: sequences | literals | Sequences_Sections | HdrSide | chunk list (fqz_hdrlz.h)
     uint32_t hcap = 0, hcap_need = 0; // headers chunks the side buffers hold / the last batch needed
+    double hcap_per_mb = 0;           // headers chunks per MiB of text of the last batch that overflowed the optimistic size
     DevBuf xmap;      // descriptors of every group (frame) for the content checksums | xsum[chunk_cap]
     DevBuf plans;     // BlockPlan[block_cap]
     DevBuf arena;     // seq/qual/hdr/plus/len pre-entropy streams

@@ -120,12 +120,17 @@ __global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *
     auto window = [&]() {
         int top = (p + 7) >> 3;
         wb = top > (int)SEQ_WIN ? (top - (int)SEQ_WIN + 3) & ~3 : 0;
-        // (a piece may read up to 15 bytes behind the stream: the frame's checksum and the payloads that follow the headers payload)
 #pragma unroll
         for (uint32_t q = 0; q < 2; q++) {
             const uint32_t piece = c + 4 * q;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (wb + (int)(16 * piece) < bn) v = load_u128_unaligned(bp + wb + 16 * piece);
+            const int at = wb + (int)(16 * piece);
+            if (at + 16 <= bn) v = load_u128_unaligned(bp + at);
+            else if (at < bn) { // the last piece of the stream: byte by byte, nothing behind the section is touched
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int k = 0; at + k < bn; k++) w[k >> 2] |= (uint32_t)bp[at + k] << (8 * (k & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
             win[4 * piece] = v.x; win[4 * piece + 1] = v.y; win[4 * piece + 2] = v.z; win[4 * piece + 3] = v.w;
         }
         if (c == 0) win[32] = 0;

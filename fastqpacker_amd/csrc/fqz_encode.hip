@@ -1342,6 +1342,10 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     // a quarter of the text being headers; a batch with more is relaunched with the exact need (fqz_enc_finish)
     uint32_t hcap = (uint32_t)(n / (4ull * FQZ_CHUNK)) + 2 * e.block_cap + 64;
     if (e.hcap_need > hcap && e.n_bytes == n_bytes) hcap = e.hcap_need;
+    if (e.hcap_per_mb > 0) { // a header-heavy input: the batches that follow one that overflowed are sized by its density
+        const unsigned long long want = (unsigned long long)(e.hcap_per_mb * ((double)n / 1048576.0) * 1.05) + 2ull * e.block_cap + 64;
+        if (want > hcap) hcap = want > main_cap ? (uint32_t)main_cap : (uint32_t)want;
+    }
     if ((size_t)hcap > main_cap) hcap = (uint32_t)main_cap;
     e.hcap = hcap;
     if ((rc = e.hside.ensure((size_t)hcap * (12ull * HDR_MAX_SEQ + FQZ_CHUNK + HDR_SEQ_CAP + sizeof(HdrSide) + 4) + 256))) return rc;
@@ -1433,6 +1437,7 @@ int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uin
     }
     if (hi->status == FQZ_E_TOO_LARGE && hi->n_hchunks > e.hcap) { // more headers chunks than side buffers: relaunch with the exact need
         e.hcap_need = hi->n_hchunks + 16;
+        e.hcap_per_mb = (double)hi->n_hchunks / ((double)(e.n_bytes ? e.n_bytes : 1) / 1048576.0);
         return FQZ_E_TOO_LARGE;
     }
     if (hi->status == FQZ_E_TOO_LARGE && hi->n_lines > e.line_cap) {
