@@ -62,14 +62,17 @@ __device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t *p)
 }
 __device__ __forceinline__ void store_u128_unaligned(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 
+// inclusive wave scan with DPP only (row shifts inside the rows of 16, then the two row broadcasts of gfx9): no trip through
+// the LDS crossbar that __shfl_up (ds_bpermute) takes - which also means it is not slowed down by kernels that saturate LDS
+#define FQZ_DPP_ADD(v, ctrl, rows) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xF, false))
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    uint32_t l = lane_id();
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, WAVE);
-        if (l >= (uint32_t)d) v += t;
-    }
+    v = FQZ_DPP_ADD(v, 0x111, 0xF); // row_shr:1
+    v = FQZ_DPP_ADD(v, 0x112, 0xF); // row_shr:2
+    v = FQZ_DPP_ADD(v, 0x114, 0xF); // row_shr:4
+    v = FQZ_DPP_ADD(v, 0x118, 0xF); // row_shr:8
+    v = FQZ_DPP_ADD(v, 0x142, 0xA); // row_bcast:15 -> rows 1 and 3
+    v = FQZ_DPP_ADD(v, 0x143, 0xC); // row_bcast:31 -> rows 2 and 3
     return v;
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
