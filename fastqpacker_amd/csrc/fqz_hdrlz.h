@@ -103,14 +103,13 @@ __device__ __forceinline__ unsigned long long hdr_ld64(const uint8_t *p) { unsig
 __device__ __forceinline__ void hdr_scan2(uint32_t a, uint32_t m, uint32_t *sh, uint32_t *ex_a, uint32_t *ex_m, uint32_t *ta, uint32_t *tm)
 {
     const uint32_t l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t ia = a, im = m;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const uint32_t xa = __shfl_up(ia, d, WAVE), xm = __shfl_up(im, d, WAVE);
-        if (l >= (uint32_t)d) { ia += xa; im = xm > im ? xm : im; }
-    }
-    uint32_t ea = __shfl_up(ia, 1, WAVE), em = __shfl_up(im, 1, WAVE);
-    if (l == 0) { ea = 0; em = 0; }
+    const uint32_t ia = wave_incl_scan(a);
+    uint32_t im = m;
+#define HDR_DPP_MAX(v, ctrl, rows) do { const uint32_t x_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xF, false); v = x_ > v ? x_ : v; } while (0)
+    HDR_DPP_MAX(im, 0x111, 0xF); HDR_DPP_MAX(im, 0x112, 0xF); HDR_DPP_MAX(im, 0x114, 0xF); HDR_DPP_MAX(im, 0x118, 0xF); // row_shr 1, 2, 4, 8
+    HDR_DPP_MAX(im, 0x142, 0xA); HDR_DPP_MAX(im, 0x143, 0xC);                                                           // row_bcast 15, 31
+#undef HDR_DPP_MAX
+    uint32_t ea = ia - a, em = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)im, 0x138, 0xF, 0xF, false); // wave_shr:1 (lane 0 gets 0)
     __syncthreads(); // (the previous use of sh)
     if (l == 63) { sh[w] = ia; sh[4 + w] = im; }
     __syncthreads();
