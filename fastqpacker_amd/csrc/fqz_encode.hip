@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 
 // ---- headers stream: model (sequences + literals per chunk), Sequences_Sections, then the entropy stage over the literals
 __global__ __launch_bounds__(256) void k_hdr_model(const EncInfo *info, const BlockPlan *plans, const uint32_t *cinfo, const uint32_t *hlist, uint32_t hcap, const uint32_t *Eh,
-                                                   const uint8_t *arena, uint2 *hseq, uint8_t *hlit, HdrSide *side)
+                                                   const uint8_t *arena, uint2 *hseq, uint8_t *hlit, HdrSide *side, uint16_t *hhist)
 {
     __shared__ __attribute__((aligned(16))) HdrModelLds S;
     const uint32_t o = blockIdx.x;
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256) void k_hdr_model(const EncInfo *info, const Bl
     const BlockPlan *p = &plans[cinfo[chunk] & 0xFFFFFFu];
     const uint32_t c0 = (chunk - p->chunk_base[S_HDR]) * FQZ_CHUNK, len = p->len[S_HDR];
     const uint32_t mk = len - c0 < FQZ_CHUNK ? len - c0 : FQZ_CHUNK;
-    hdr_model_chunk(S, arena + p->a_off[S_HDR], Eh, p->rec0, p->nrec, c0, mk, hseq + (size_t)o * HDR_MAX_SEQ, hlit + (size_t)o * FQZ_CHUNK, &side[o]);
+    hdr_model_chunk(S, arena + p->a_off[S_HDR], Eh, p->rec0, p->nrec, c0, mk, hseq + (size_t)o * HDR_MAX_SEQ, hlit + (size_t)o * FQZ_CHUNK, &side[o], hhist + (size_t)o * 256);
 }
 
 __global__ __launch_bounds__(64) void k_hdr_seq1(const EncInfo *info, uint32_t hcap, const uint2 *hseq, uint32_t *hst, HdrSide *side)
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(64) void k_hdr_seq2(const EncInfo *info, uint32_t h
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_entropy_hdr(const EncInfo *info, const uint4 *hmap, const uint8_t *arena, uint8_t *slots, uint32_t *csize,
-                                                     const uint32_t *hord, uint32_t hcap, const uint8_t *hlit, const HdrSide *side)
+                                                     const uint32_t *hord, uint32_t hcap, const uint8_t *hlit, const HdrSide *side, const uint16_t *hhist)
 {
     __shared__ __attribute__((aligned(16))) EntropyLds S;
     __shared__ HdrGroup H;
@@ -936,6 +936,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if (o < hcap) sd = side[o];
         H.nseq[t] = sd.nseq; H.n_lit[t] = sd.nseq ? sd.n_lit : mk;
         H.lit[t] = sd.nseq ? hlit + (size_t)o * FQZ_CHUNK : src + (size_t)t * FQZ_CHUNK;
+        H.hist[t] = hhist + (size_t)(o < hcap ? o : 0) * 256;
     }
     __syncthreads();
     entropy_encode_group<true>(S, src, M, 0u, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], 0, nullptr, &H);
@@ -1348,12 +1349,13 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     }
     if ((size_t)hcap > main_cap) hcap = (uint32_t)main_cap;
     e.hcap = hcap;
-    if ((rc = e.hside.ensure((size_t)hcap * (12ull * HDR_MAX_SEQ + FQZ_CHUNK + HDR_SEQ_CAP + sizeof(HdrSide) + 4) + 256))) return rc;
+    if ((rc = e.hside.ensure((size_t)hcap * (12ull * HDR_MAX_SEQ + FQZ_CHUNK + HDR_SEQ_CAP + sizeof(HdrSide) + 4 + 512) + 256))) return rc;
     uint2 *hseq = e.hside.as<uint2>();
     uint32_t *hst = (uint32_t *)(hseq + (size_t)hcap * HDR_MAX_SEQ);
     uint8_t *hlit = (uint8_t *)(hst + (size_t)hcap * HDR_MAX_SEQ), *hsec = hlit + (size_t)hcap * FQZ_CHUNK;
     HdrSide *hside = (HdrSide *)(hsec + (size_t)hcap * HDR_SEQ_CAP);
     uint32_t *hlist = (uint32_t *)(hside + hcap);
+    uint16_t *hhist = (uint16_t *)(hlist + hcap);
     PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), hmap, e.xmap.as<uint4>(), group_cap,
                                                     cinfo, csize, hord, hlist, hcap));
     // the content checksums need the streams only: they are hashed on a side stream beside the entropy coder (a chain of
@@ -1381,7 +1383,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0)); // (the checksums need the streams only)
     PROF(ctx, sd2, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd2, info, e.xmap.as<uint4>(), arena, npos, xsum));
     HIP_TRY(hipEventRecord(e.ev_join2, e.side2));
-    PROF(ctx, st, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, st, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside));
+    PROF(ctx, st, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, st, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside, hhist));
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side, e.ev_fork, 0));
     HIP_TRY(hipStreamWaitEvent(e.side3, e.ev_fork, 0));
@@ -1390,7 +1392,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, sd3, "k_hdr_seq1", hipLaunchKernelGGL(k_hdr_seq1, dim3((hcap + 15) / 16), dim3(64), 0, sd3, info, hcap, hseq, hst, hside));
     PROF(ctx, sd3, "k_hdr_seq2", hipLaunchKernelGGL(k_hdr_seq2, dim3(hcap), dim3(64), 0, sd3, info, hcap, hseq, hst, hsec, hside));
     HIP_TRY(hipEventRecord(e.ev_join3, e.side3));
-    PROF(ctx, sd, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, sd, info, hmap, arena, slots, csize, hord, hcap, hlit, hside));
+    PROF(ctx, sd, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, sd, info, hmap, arena, slots, csize, hord, hcap, hlit, hside, hhist));
     HIP_TRY(hipEventRecord(e.ev_join, e.side));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join, 0));

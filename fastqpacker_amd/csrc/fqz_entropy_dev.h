@@ -355,6 +355,7 @@ __device__ __forceinline__ void load_chunk_syms(EntropyLds &S, const uint8_t *sr
 // sequences has lit = the chunk itself.
 struct HdrGroup {
     const uint8_t *lit[FQZ_GROUP];
+    const uint16_t *hist[FQZ_GROUP]; // byte histogram of the chunk's literals (k_hdr_model counted them while it compacted them)
     uint32_t n_lit[FQZ_GROUP], nseq[FQZ_GROUP];
 };
 #define HDR_SSZ_BOUND(n) (((n) < 128u ? 2u : 3u) + ((n) * 66u + 18u + 7u) / 8u)
@@ -374,8 +375,17 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
     //      in registers and added once per wave.
     S.ctab[t] = 0;
     uint32_t same_mask = 0; // bit k: chunk k is one repeated byte
+    if (HDR) { // the histograms come with the literals: no pass over them here
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < nchunk; k++) {
+            const uint32_t h = H->hist[k][t];
+            c += h;
+            if (__syncthreads_count(h != 0) == 1 && !H->nseq[k]) same_mask |= 1u << k;
+        }
+        S.ctab[t] = c;
+    }
 #pragma clang loop unroll(disable)
-    for (uint32_t k = 0; k < (force_raw ? 0u : nchunk); k++) {
+    for (uint32_t k = 0; k < ((force_raw || HDR) ? 0u : nchunk); k++) {
         const uint32_t mk = M - k * FQZ_CHUNK < FQZ_CHUNK ? M - k * FQZ_CHUNK : FQZ_CHUNK;
         const uint8_t *csrc = HDR ? H->lit[k] : src + (size_t)k * FQZ_CHUNK;
         ChunkSyms C;

@@ -96,6 +96,7 @@ struct HdrModelLds {
     uint32_t q_n;           // long literal runs (> HDR_RUN_MAX bytes) of the strip: all threads copy them
     uint32_t q[FQZ_CHUNK / HDR_RUN_MAX + 4][3]; // {source (chunk-relative), destination (literal offset), bytes}; a chunk cannot hold more
     __attribute__((aligned(16))) uint8_t stage[HDR_STAGE + 16];
+    uint32_t hist[256];     // byte histogram of the chunk's literals (the entropy stage builds its table from these)
 };
 __device__ __forceinline__ unsigned long long hdr_ld64(const uint8_t *p) { unsigned long long v; __builtin_memcpy(&v, p, 8); return v; }
 
@@ -124,9 +125,19 @@ __device__ __forceinline__ void hdr_scan2(uint32_t a, uint32_t m, uint32_t *sh, 
 }
 
 __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stream, const uint32_t *__restrict__ Eh, uint32_t rec0, uint32_t nrec,
-                                uint32_t c0, uint32_t mk, uint2 *__restrict__ hseq, uint8_t *__restrict__ hlit, HdrSide *side)
+                                uint32_t c0, uint32_t mk, uint2 *__restrict__ hseq, uint8_t *__restrict__ hlit, HdrSide *side, uint16_t *__restrict__ hhist)
 {
     const uint32_t t = threadIdx.x;
+    S.hist[t] = 0;
+    // the whole chunk is its own literal run (no sequences): histogram of the text in LDS; ends with the counts in hhist
+    auto hist_all = [&]() {
+        for (uint32_t i = t * 4; i < mk; i += 256 * 4) {
+            const uint32_t w = *(const uint32_t *)&S.text[HDR_TPAD + i], n = mk - i < 4 ? mk - i : 4;
+            for (uint32_t q = 0; q < n; q++) atomicAdd(&S.hist[(w >> (8 * q)) & 0xFF], 1u);
+        }
+        __syncthreads();
+        hhist[t] = (uint16_t)S.hist[t];
+    };
     const uint32_t base_e = Eh[rec0], c1 = c0 + mk;
     uint8_t *const text = S.text + HDR_TPAD;
     for (uint32_t i = t * 16; i < mk; i += 256 * 16) *(uint4 *)&text[i] = load_u128_unaligned(stream + c0 + i); // (in flight during the search)
@@ -154,7 +165,12 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
     }
     uint32_t n_in = last1 > first ? last1 - first : 0;
     if (2 * n_in > HDR_MAX_SEQ) n_in = 0;
-    if (n_in < 2) { if (t == 0) { side->nseq = 0; side->n_lit = mk; side->sec_len = 0; side->pad = 0; } return; }
+    if (n_in < 2) {
+        if (t == 0) { side->nseq = 0; side->n_lit = mk; side->sec_len = 0; side->pad = 0; }
+        __syncthreads(); // (the text is in LDS)
+        hist_all();
+        return;
+    }
     for (uint32_t k = t; k <= n_in; k += 256) S.e[k] = (uint16_t)(Eh[rec0 + first + k] - base_e - c0);
     if (t == 0) { S.carry[0] = S.carry[1] = 0; S.q_n = 0; }
     if (t < 4) ((uint32_t *)S.text)[t] = 0;
@@ -236,14 +252,14 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
             const uint32_t w_end = a0 + HDR_STAGE;
             auto put = [&](uint32_t src, uint32_t dst, uint32_t ll) {
                 const uint32_t a = dst > a0 ? dst : a0, b = dst + ll < w_end ? dst + ll : w_end;
-                for (uint32_t j = a; j < b; j++) S.stage[j - a0] = text[src + (j - dst)];
+                for (uint32_t j = a; j < b; j++) { const uint8_t v = text[src + (j - dst)]; S.stage[j - a0] = v; atomicAdd(&S.hist[v], 1u); }
             };
             if (llA) put(srcA, dstA, llA);
             if (llB) put(srcB, dstB, llB);
             for (uint32_t qi = 0; qi < qn; qi++) { // long runs: all threads copy
                 const uint32_t src = S.q[qi][0], dst = S.q[qi][1], ll = S.q[qi][2];
                 const uint32_t a = dst > a0 ? dst : a0, b = dst + ll < w_end ? dst + ll : w_end;
-                for (uint32_t j = a + t; j < b; j += 256) S.stage[j - a0] = text[src + (j - dst)];
+                for (uint32_t j = a + t; j < b; j += 256) { const uint8_t v = text[src + (j - dst)]; S.stage[j - a0] = v; atomicAdd(&S.hist[v], 1u); }
             }
             __syncthreads();
             const uint32_t have_end = lit_end < w_end ? lit_end : w_end, flush_end = have_end & ~15u;
@@ -264,8 +280,10 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
     if (nseq) {
         const uint32_t lit_end = last_end - matched;
         if (t < lit_end - a0) hlit[a0 + t] = S.stage[t];
-        for (uint32_t j = last_end + t; j < mk; j += 256) hlit[j - matched] = text[j];
-    }
+        for (uint32_t j = last_end + t; j < mk; j += 256) { const uint8_t v = text[j]; hlit[j - matched] = v; atomicAdd(&S.hist[v], 1u); }
+        __syncthreads();
+        hhist[t] = (uint16_t)S.hist[t];
+    } else hist_all(); // (records inside, but no candidate long enough)
     if (t == 0) { side->nseq = nseq; side->n_lit = mk - matched; side->sec_len = 0; side->pad = 0; }
 }
 
