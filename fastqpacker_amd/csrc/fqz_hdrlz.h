@@ -63,9 +63,6 @@ constexpr short HDR_LL_NORM[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 
 constexpr short HDR_ML_NORM[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
                                    1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
 constexpr short HDR_OF_NORM[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
-__constant__ const HdrCt c_hdr_ll = hdr_make_ct(HDR_LL_NORM, 6);
-__constant__ const HdrCt c_hdr_ml = hdr_make_ct(HDR_ML_NORM, 6);
-__constant__ const HdrCt c_hdr_of = hdr_make_ct(HDR_OF_NORM, 5);
 __constant__ const uint32_t c_hll_base[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40,
                                               48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
 __constant__ const uint8_t c_hll_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
