@@ -1203,6 +1203,7 @@ __global__ __launch_bounds__(1024) void k_dec_walk0(const uint8_t *arena, DecInf
             }
         }
         if (!__syncthreads_or(bad != 0)) { for (uint32_t r = t; r < nrec; r += 1024) out[r] = 2 * r; mode = 1; }
+        else { if (t == 0) dec_fail(info, walk_err((int)which)); return; } // nrec prefixes fill the stream, so a payload behind any of them runs past its end
     } else if (nrec == 0) mode = 1;
     if (mode == 0 && b->samp_off[s]) mode = 2; // the index carries record samples: k_dec_walk_s
     if (t == 0) b->walk_mode[which] = mode;
@@ -1973,7 +1974,17 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         const uint32_t xper = (max_sgroups + 63) / 64;
         PROF(ctx, st, "k_dec_walk_s", hipLaunchKernelGGL(k_dec_walk_s, dim3(xper * nb * 3), dim3(64), 0, st, d_in, darena, info, blocks, offs, ostride, xper));
     }
-    if (n_tiles) {
+    // the tiled walks are only for chains that neither a rule (k_dec_walk0) nor record samples (k_dec_walk_s) resolve
+    bool need_walks = false;
+    for (uint32_t b = 0; b < nb && !need_walks; b++) {
+        const int ws[3] = {S_HDR, S_PLUS, S_NPOS};
+        for (int w = 0; w < 3; w++) {
+            const int s = ws[w];
+            const bool by_rule = hb[b].nrec == 0 || (unsigned long long)hb[b].raw_len[s] == 2ull * hb[b].nrec || (s == S_PLUS && hb[b].raw_len[s] == 0);
+            if (!by_rule && !hb[b].samp_off[s]) need_walks = true;
+        }
+    }
+    if (n_tiles && need_walks) {
         PROF(ctx, st, "k_dec_walk1", hipLaunchKernelGGL(k_dec_walk1, dim3(n_tiles), dim3(256), 0, st, darena, info, blocks, n_tiles, walkF));
         PROF(ctx, st, "k_dec_walk2", hipLaunchKernelGGL(k_dec_walk2, dim3(nb * 3), dim3(64), 0, st, darena, info, blocks, walkF, walkE));
         PROF(ctx, st, "k_dec_walk3", hipLaunchKernelGGL(k_dec_walk3, dim3(n_tiles), dim3(64), 0, st, darena, info, blocks, n_tiles, walkE, offs, ostride));
