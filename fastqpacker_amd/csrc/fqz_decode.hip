@@ -1795,13 +1795,17 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         HIP_TRY(hipMemsetAsync(blocks, 0, sizeof(DecBlock) * (size_t)cap0, st));
         PROF(ctx, st, "k_dec_blocks", hipLaunchKernelGGL(k_dec_blocks, dim3(1), dim3(64), 0, st, d_in, n, (uint32_t)version, info, blocks, cap0));
         PROF(ctx, st, "k_dec_fhdr", hipLaunchKernelGGL(k_dec_fhdr, dim3((cap0 * FQZ_NS + 63) / 64), dim3(64), 0, st, d_in, info, blocks, cap0));
+        const uint32_t pre = 256; // (the first blocks travel with the counters: one round trip for ordinary batches)
         HIP_TRY(hipMemcpyAsync(hi, info, sizeof(DecInfo), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(d.h_blocks.p, blocks, sizeof(DecBlock) * (size_t)pre, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (hi->status) return hi->status;
         nb = hi->n_blocks; n_rec = hi->n_rec;
         if (nb && nb <= cap0) {
-            HIP_TRY(hipMemcpyAsync(d.h_blocks.p, blocks, sizeof(DecBlock) * (size_t)nb, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            if (nb > pre) {
+                HIP_TRY(hipMemcpyAsync(d.h_blocks.as<DecBlock>() + pre, blocks + pre, sizeof(DecBlock) * (size_t)(nb - pre), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            }
             have_table = true;
         }
     } else {

@@ -248,14 +248,16 @@ __global__ __launch_bounds__(256) void k_line_local(const uint8_t *__restrict__ 
     const uint32_t tile = blockIdx.x * 4 + wave;
     if (tile >= n_tiles) return; // (whole waves leave; the kernel has no workgroup barrier)
     const uint32_t tbase = tile * FQZ_TILE;
-    uint32_t m[4][4], c[4];
+    uint32_t m[4], c[4]; // per row of 16 bytes: one bit per byte that is a newline
 #pragma unroll
     for (uint32_t q = 0; q < 4; q++) {
         const uint4 v = load_text16(text, tbase + q * 1024 + 16 * lane, n);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        c[q] = 0;
+        m[q] = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { m[q][k] = zero_bytes(w[k] ^ 0x0A0A0A0Au); c[q] += __popc(m[q][k]); }
+        for (int k = 0; k < 4; k++) // 0x80 per matching byte -> 4 bits (the multiply gathers bits 7, 15, 23, 31 at bits 21..24)
+            m[q] |= ((((zero_bytes(w[k] ^ 0x0A0A0A0Au) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * k);
+        c[q] = __popc(m[q]);
         if (tile == 0 && q == 0 && lane == 0) {
             ls[0] = 0;
             lf[0] = (uint8_t)(n ? (((v.x & 0xFF) == '@' ? 1 : (v.x & 0xFF) == '+' ? 2 : 0) << 1) : 0);
@@ -276,16 +278,12 @@ __global__ __launch_bounds__(256) void k_line_local(const uint8_t *__restrict__ 
     uint16_t *list = s_pos[wave];
 #pragma unroll
     for (uint32_t q = 0; q < 4; q++) {
-        uint32_t idx = excl[q];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t mk = m[q][k];
-            while (mk) {
-                const uint32_t bit = (uint32_t)__ffs(mk) - 1; // 7, 15, 23, 31
-                mk &= mk - 1;
-                if (idx < LL_CAP) list[idx] = (uint16_t)(q * 1024 + 16 * lane + 4 * k + (bit >> 3));
-                idx++;
-            }
+        uint32_t idx = excl[q], mk = m[q];
+        while (mk) {
+            const uint32_t bit = (uint32_t)__ffs(mk) - 1; // byte of the row
+            mk &= mk - 1;
+            if (idx < LL_CAP) list[idx] = (uint16_t)(q * 1024 + 16 * lane + bit);
+            idx++;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
