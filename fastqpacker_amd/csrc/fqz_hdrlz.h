@@ -330,7 +330,7 @@ constexpr HdrTrans hdr_make_all_trans()
 __constant__ const HdrTrans c_hdr_trans = hdr_make_all_trans();
 // what a chain needs for one sequence in ONE 64-bit LDS read, indexed by the value itself when it is small (literal length
 // < 64, match length - 3 < 128: nearly always) and by 64 / 128 + code otherwise; offsets: by code.
-// x = the symbol's candidate next states, y = deltaNbBits | count << 24
+// x = the symbol's candidate next states, y = deltaNbBits (20 bits) | count << 20 | code << 23
 struct HdrChainLds {
     uint2 ll[64 + 36], ml[128 + 53], of[32];
 };
@@ -343,7 +343,7 @@ __device__ __forceinline__ uint32_t hdr_ofv(const uint2 cur, const uint2 prev, b
 __device__ __forceinline__ void hdr_chain_tables(HdrChainLds &T)
 {
     const uint32_t lane = threadIdx.x;
-    auto entry = [](int chain, uint32_t code) { return make_uint2(c_hdr_trans.cand[chain][code], (uint32_t)c_hdr_trans.dnb[chain][code] | ((uint32_t)c_hdr_trans.cnt[chain][code] << 24)); };
+    auto entry = [](int chain, uint32_t code) { return make_uint2(c_hdr_trans.cand[chain][code], (uint32_t)c_hdr_trans.dnb[chain][code] | ((uint32_t)c_hdr_trans.cnt[chain][code] << 20) | (code << 23)); };
     T.ll[lane] = entry(0, c_hll_code[lane]);
     if (lane < 36) T.ll[64 + lane] = entry(0, lane);
     T.ml[lane] = entry(1, c_hml_code[lane]);
@@ -367,31 +367,31 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
 {
     uint32_t st = 0;
     const uint32_t cc = c < 3 ? c : 2u; // (the idle lane walks along with the offsets chain: its results are dropped)
-    for (int hi = on ? (int)nseq - 1 : -1; hi >= 0; hi -= (int)HDR_CB) {
-        uint2 buf[HDR_CB + 1];
+    const uint32_t tsize = cc == 2 ? 32u : 64u;
+    // trips over aligned groups of HDR_CB sequences, from the last group down: 16-byte loads (two sequences each), all in flight
+    for (int base = on ? ((int)nseq - 1) / (int)HDR_CB * (int)HDR_CB : -1; base >= 0; base -= (int)HDR_CB) {
+        uint4 pr[HDR_CB / 2];
 #pragma unroll
-        for (int j = 0; j <= (int)HDR_CB; j++) { const int idx = hi - j; buf[j] = idx >= 0 ? hseq[idx] : make_uint2(3u << 16, 0); }
-        uint2 ent[HDR_CB]; // of the symbol of this lane's chain for sequence hi - j
-        const uint32_t tsize = cc == 2 ? 32u : 64u;
+        for (int k = 0; k < (int)HDR_CB / 2; k++) pr[k] = ((const uint4 *)(hseq + base))[k]; // (past nseq: inside the side buffers, not used)
+        const uint2 prev0 = base > 0 ? hseq[base - 1] : make_uint2(0, 0);
+        uint2 ent[HDR_CB]; // of the symbol of this lane's chain for sequence base + j
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) {
-            const uint2 cur = buf[j];
+            const bool live = base + j < (int)nseq;
+            uint2 cur = (j & 1) ? make_uint2(pr[j >> 1].z, pr[j >> 1].w) : make_uint2(pr[j >> 1].x, pr[j >> 1].y);
+            if (!live) cur = make_uint2(3u << 16, 0);
+            const uint2 prv = j ? ((j & 1) ? make_uint2(pr[j >> 1].x, pr[j >> 1].y) : make_uint2(pr[(j - 1) >> 1].z, pr[(j - 1) >> 1].w)) : prev0;
             if (cc == 0) { const uint32_t ll = cur.x & 0xFFFFu; ent[j] = T.ll[ll < 64 ? ll : 64u + (uint32_t)highbit32_d(ll) + 19u]; }
             else if (cc == 1) { const uint32_t mlb = (cur.x >> 16) - 3; ent[j] = T.ml[mlb < 128 ? mlb : 128u + (uint32_t)highbit32_d(mlb) + 36u]; }
-            else ent[j] = T.of[(uint32_t)highbit32_d(hdr_ofv(cur, buf[j + 1], hi - j > 0)) & 31u];
-        }
-        if (hi == (int)nseq - 1) { // the last sequence opens the chain: no output
-            const uint2 cur = buf[0];
-            const uint32_t ll = cur.x & 0xFFFFu, mlb = (cur.x >> 16) - 3;
-            const uint32_t code = cc == 0 ? (ll < 64 ? c_hll_code[ll] : (uint32_t)highbit32_d(ll) + 19u)
-                                          : (cc == 1 ? (mlb < 128 ? c_hml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36u) : (uint32_t)highbit32_d(hdr_ofv(cur, buf[1], hi > 0)));
-            st = c_hdr_trans.init[cc][code];
+            else ent[j] = T.of[(uint32_t)highbit32_d(hdr_ofv(cur, prv, base + j > 0)) & 31u];
         }
         uint32_t outv[HDR_CB];
 #pragma unroll
-        for (int j = 0; j < (int)HDR_CB; j++) { // the walk: registers only
-            const bool live = hi - j >= 0, first = hi - j == (int)nseq - 1;
-            const uint32_t full = st + tsize, nb = (full + (ent[j].y & 0xFFFFFFu)) >> 16, k = ((full >> nb) - ((ent[j].y >> 24) & 7u)) & 3u;
+        for (int j = (int)HDR_CB - 1; j >= 0; j--) { // the walk, last sequence of the group first: registers only
+            const bool live = base + j < (int)nseq, first = base + j == (int)nseq - 1;
+            const uint32_t y = ent[j].y;
+            if (first) st = c_hdr_trans.init[cc][(y >> 23) & 63u]; // the last sequence opens the chain: no output
+            const uint32_t full = st + tsize, nb = (full + (y & 0xFFFFFu)) >> 16, k = ((full >> nb) - ((y >> 20) & 7u)) & 3u;
             const uint32_t nxt = (ent[j].x >> (8 * k)) & 0xFFu;
             outv[j] = first ? 0u : ((st & ((1u << nb) - 1)) | (nb << 6));
             st = (live && !first) ? nxt : st;
@@ -399,7 +399,7 @@ __device__ void hdr_seq_chains(HdrChainLds &T, const uint2 *__restrict__ hseq, u
 #pragma unroll
         for (int j = 0; j < (int)HDR_CB; j++) {
             const uint32_t v = hdr_quad<0>(outv[j]) | (hdr_quad<1>(outv[j]) << 9) | (hdr_quad<2>(outv[j]) << 18);
-            if (c == 0 && hi - j >= 0) hst[hi - j] = v;
+            if (c == 0 && base + j < (int)nseq) hst[base + j] = v;
         }
     }
     const uint32_t fin = hdr_quad<0>(st) | (hdr_quad<1>(st) << 8) | (hdr_quad<2>(st) << 16);
