@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *
     const uint32_t cc = c == 3 ? 2u : c; // (the idle lane walks along with the offsets chain: its results are dropped)
     const uint32_t m_lt2 = cc < 2 ? ~0u : 0u, m_lt1 = cc < 1 ? ~0u : 0u, m_ge1 = cc >= 1 ? ~0u : 0u, m_ge2 = cc >= 2 ? ~0u : 0u;
     uint32_t bad_profile = 0, bad_data = 0;
+    uint2 held = make_uint2(0, 0);
     for (uint32_t i = 0; i < (verdict ? 0u : nseq); i++) { // one rarely-taken branch a step; everything else is straight-line
         if (p - 80 < 8 * wb && wb > 0) window();
         const uint2 e = T.tab[cc][st & 63];
@@ -178,7 +179,11 @@ __global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *
         prev_off = offset;
         bad_data |= (ll > ch.regen - lit_used) | (ll > ch.out_len - o) | (ml > ch.out_len - o - ll);
         bad_profile |= offset > o + ll; // reaches in front of the block: not ours
-        if (c == 0) out[i] = make_uint2(ll | (ml << 16), offset);
+        // two triples a store (16 bytes): half the store instructions in a kernel that runs beside the Huffman decode
+        const uint2 cur = make_uint2(ll | (ml << 16), offset);
+        if (c == 0 && (i & 1)) *(uint4 *)&out[i - 1] = make_uint4(held.x, held.y, cur.x, cur.y);
+        if (c == 0 && last && !(i & 1)) out[i] = cur;
+        held = cur;
         lit_used += ll;
         o += ll + ml;
         if (bad_profile | bad_data) break;
