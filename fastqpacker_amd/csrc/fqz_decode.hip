@@ -1932,12 +1932,17 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     // at the end needs the bases and qualities too.  The latter are 3/4 of the entropy decode and the walks leave the
     // chip almost empty, so the two run side by side: bases + qualities on the context's side stream, joined before
     // k_dec_assemble (285 -> 295 GB/s over 30 decodes, A/B on one box).
-    const uint32_t early = (1u << S_HDR) | (1u << S_PLUS) | (1u << S_NPOS) | (1u << S_LEN), late = (1u << S_SEQ) | (1u << S_QUAL);
+    // (the packed bases are Raw blocks in our files - a plain copy: it rides on the caller's stream, which has slack beside
+    //  the record walks, and leaves the side stream to the Huffman decode of the qualities, the longest item of the decode)
+    const uint32_t early = (1u << S_HDR) | (1u << S_PLUS) | (1u << S_NPOS) | (1u << S_LEN) | (1u << S_SEQ), late = 1u << S_QUAL;
     bool forked = false;
     if (n_chunks) {
         const int dbg = getenv("FQZ_DBG_DEC") ? atoi(getenv("FQZ_DBG_DEC")) : 0;
         if (!d.side) {
-            HIP_TRY(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking)); // (a low-priority side stream measured the same)
+            int prio_lo = 0, prio_hi = 0; // the side stream yields to the caller's stream, whose chain of kernels decides when the text can be assembled
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            HIP_TRY(hipStreamCreateWithPriority(&d.side, hipStreamNonBlocking, prio_lo));
+            HIP_TRY(hipEventCreateWithFlags(&d.ev_joinx, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
             HIP_TRY(hipStreamCreateWithFlags(&d.side2, hipStreamNonBlocking));
@@ -1962,14 +1967,15 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         }
         PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late));
         PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, sd, d_in, info, dch, darena, late));
-        if (n_frames) { // content checksums of the decoded frames, all on the side stream: nothing on the caller's stream needs them
-            // before the text is assembled (the early streams are complete once the sequences have been executed: ev_x)
+        HIP_TRY(hipEventRecord(d.ev_join, d.side)); // the qualities are decoded: the text can be assembled
+        if (n_frames) { // content checksums of the decoded frames, all on the side stream: nothing needs them before the verdict at the
+            // end, so they run beside the text assembly (the early streams are complete once the sequences have been executed: ev_x)
             HIP_TRY(hipEventRecord(d.ev_x, st));
             PROF(ctx, sd, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, sd, d_in, info, dfr, n_frames, darena, late));
             HIP_TRY(hipStreamWaitEvent(d.side, d.ev_x, 0));
             PROF(ctx, sd, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, sd, d_in, info, dfr, n_frames, darena, early));
         }
-        HIP_TRY(hipEventRecord(d.ev_join, d.side));
+        HIP_TRY(hipEventRecord(d.ev_joinx, d.side));
         forked = true;
     }
     if (n_lz) PROF(ctx, st, "k_dec_lz", hipLaunchKernelGGL(k_dec_lz, dim3(fgrid), dim3(64), 0, st, d_in, info, blocks, darena, d.lz_scratch.as<uint8_t>()));
@@ -2015,6 +2021,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         if (!skip_assemble) PROF(ctx, st, "k_dec_assemble", hipLaunchKernelGGL(k_dec_assemble, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride, qoff, d_out));
     }
     if (forked) HIP_TRY(hipStreamWaitEvent(st, d.ev_join, 0)); // (no records: nothing assembled, still join)
+    if (n_chunks) HIP_TRY(hipStreamWaitEvent(st, d.ev_joinx, 0)); // the checksums: before the status is read
     HIP_TRY(hipGetLastError());
     // keep the host-side per-stream totals; status / out_len come back after the tail
     HIP_TRY(hipMemcpyAsync(&hi->status, &info->status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
