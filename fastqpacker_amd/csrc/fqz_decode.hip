@@ -864,14 +864,17 @@ struct HufGroupLds {
     uint16_t ss[16];            // ss[w]: first position in syms[] of weight w
 };
 
-__global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info, DecChunk *chunks, uint8_t *arena, int dbg, uint32_t stream_mask)
+// (the launch covers the chunks [first, first + count): the host numbers the chunks of the quality streams first, so that the
+//  launch for them and the launch for the other streams are both dense)
+__global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info, DecChunk *chunks, uint8_t *arena, int dbg, uint32_t stream_mask,
+                                                uint32_t first, uint32_t count)
 {
     __shared__ HufGroupLds G[HG];
     __shared__ uint32_t obuf[16 * 64]; // per-lane 64-byte output staging, transposed: dword j of lane l at [j*64 + l]
     const uint32_t lane = threadIdx.x, grp = lane >> 2, sub = lane & 3;
-    const uint32_t id = blockIdx.x * HG + grp;
+    const uint32_t id = first + blockIdx.x * HG + grp;
     if (info->status) return;
-    const bool have = id < info->n_chunks;
+    const bool have = id < first + count && id < info->n_chunks;
     DecChunk c;
     c.btype = 0;
     if (have) c = chunks[id];
@@ -1083,13 +1086,13 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
     if (ok && sub == 0 && !fail) chunks[id].btype = 3; // done: the general kernel skips it
 }
 
-__global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena, uint32_t stream_mask)
+__global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena, uint32_t stream_mask, uint32_t first)
 {
     __shared__ uint16_t s_dt[4096];
     __shared__ uint8_t s_w[260];
     __shared__ uint8_t s_scratch[256];
     __shared__ int s_i[8]; // 0 table log, 1 tree bytes used (or -1), 2..5 per-stream result
-    const uint32_t id = blockIdx.x;
+    const uint32_t id = first + blockIdx.x;
     if (id >= info->n_chunks || info->status) return;
     const DecChunk c = chunks[id];
     if (c.btype == 3 || !((stream_mask >> c.stream) & 1u)) return; // decoded by k_dec_huf / another launch's stream
@@ -1850,12 +1853,15 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     unsigned long long arena = 0, chunks = 0, out_bound = 0, tiles = 0, n_lz = 0, nframes = 0;
     bool any_indexed = false;
     for (int s = 0; s < FQZ_NS; s++) { hi->stream_raw[s] = 0; hi->stream_comp[s] = 0; }
+    // chunk numbers: the quality streams of all blocks first, then the other streams block by block - the two entropy launches
+    // (qualities on the side stream, the rest on the caller's) then each cover a dense range
+    unsigned long long qchunks = 0;
+    for (uint32_t b = 0; b < nb; b++) { hb[b].chunk_base[S_QUAL] = (uint32_t)qchunks; qchunks += hb[b].n_chunks[S_QUAL]; }
     for (uint32_t b = 0; b < nb; b++) {
         for (int s = 0; s < FQZ_NS; s++) {
             hb[b].a_off[s] = (uint32_t)arena;
             arena += ((unsigned long long)hb[b].raw_len[s] + 15 + 16) & ~15ull; // +16: tile loads read whole uint4
-            hb[b].chunk_base[s] = (uint32_t)chunks;
-            chunks += hb[b].n_chunks[s];
+            if (s != S_QUAL) { hb[b].chunk_base[s] = (uint32_t)(qchunks + chunks); chunks += hb[b].n_chunks[s]; }
             hb[b].frame_base[s] = (uint32_t)nframes;
             nframes += hb[b].n_frames[s];
             if (general) { hb[b].indexed[s] = 0; hb[b].samp_off[s] = 0; } // the general path walks every payload and every chain, index or not
@@ -1893,6 +1899,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         if (2ull * nr > hb[b].raw_len[S_HDR]) return FQZ_E_TRUNC_HEADER;
         if (hb[b].raw_len[S_PLUS] && 2ull * nr > hb[b].raw_len[S_PLUS]) return FQZ_E_TRUNC_PLUS;
     }
+    chunks += qchunks;
     if (arena > 0xFFFFFFF0ull || chunks > 0x7FFFFFFFull || out_bound > 0xFFFFFFF0ull || tiles > 0x7FFFFFFFull || nframes > 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
     const uint32_t n_tiles = (uint32_t)tiles;
     const bool skip_assemble = d.skip_assemble;
@@ -1903,7 +1910,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     }
     if (skip_assemble) out_cap = 0xFFFFFFF0ull; // nothing is written: only the total is reported
     d.d_out = d_out; d.out_cap = out_cap;
-    const uint32_t n_chunks = (uint32_t)chunks;
+    const uint32_t n_chunks = (uint32_t)chunks, n_q = (uint32_t)qchunks, n_o = n_chunks - n_q; // all / quality / other chunks
     const uint32_t ostride = n_rec + 1, cstride = n_rec + 1;
     if ((rc = d.streams.ensure((size_t)arena + 64))) return rc;
     if (n_lz && (rc = d.lz_scratch.ensure((size_t)n_lz * LZ_SCRATCH))) return rc;
@@ -1954,17 +1961,21 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         if (any_seq) { // the sequence bit streams need the input only: a chain of serial steps, beside the literals' Huffman decode
             const hipStream_t s2 = dbg_serial ? st : d.side2;
             HIP_TRY(hipStreamWaitEvent(d.side2, d.ev_fork, 0));
-            PROF(ctx, s2, "k_dec_seq_fse", hipLaunchKernelGGL(k_dec_seq_fse, dim3((n_chunks + 15) / 16), dim3(64), 0, s2, d_in, info, dch, darena));
+            PROF(ctx, s2, "k_dec_seq_fse", hipLaunchKernelGGL(k_dec_seq_fse, dim3((n_o + 15) / 16), dim3(64), 0, s2, d_in, info, dch, darena, n_q));
             HIP_TRY(hipEventRecord(d.ev_join2, d.side2));
         }
-        PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, st, d_in, info, dch, darena, dbg, early));
-        PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, st, d_in, info, dch, darena, early));
+        if (n_o) {
+            PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_o + HG - 1) / HG), dim3(64), 0, st, d_in, info, dch, darena, dbg, early, n_q, n_o));
+            PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_o), dim3(64), 0, st, d_in, info, dch, darena, early, n_q));
+        }
         if (any_seq) { // headers blocks with sequences: their literals are in the scratch now, their triples come from side2
             HIP_TRY(hipStreamWaitEvent(st, d.ev_join2, 0));
-            PROF(ctx, st, "k_dec_seq_exec", hipLaunchKernelGGL(k_dec_seq_exec, dim3(n_chunks), dim3(64), 0, st, info, dch, darena));
+            PROF(ctx, st, "k_dec_seq_exec", hipLaunchKernelGGL(k_dec_seq_exec, dim3(n_o), dim3(64), 0, st, info, dch, darena, n_q));
         }
-        PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_chunks + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late));
-        PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_chunks), dim3(64), 0, sd, d_in, info, dch, darena, late));
+        if (n_q) {
+            PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_q + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late, 0u, n_q));
+            PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_q), dim3(64), 0, sd, d_in, info, dch, darena, late, 0u));
+        }
         HIP_TRY(hipEventRecord(d.ev_join, d.side)); // the qualities are decoded: the text can be assembled
         if (n_frames) { // content checksums of the decoded frames, all on the side stream: nothing needs them before the verdict at the
             // end, so they run beside the text assembly (367 -> 390 GB/s, A/B on one box; the early streams are complete once the
@@ -2104,8 +2115,8 @@ int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     HIP_TRY(hipMemcpyAsync(&info->n_chunks, &hi->n_chunks, 4, hipMemcpyHostToDevice, st));
     PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, d.chunks.as<DecChunk>(), d.frames.as<DecFrame>(), 1));
     if (nch) {
-        PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((nch + HG - 1) / HG), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0, 0x3Fu));
-        PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(nch), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0x3Fu));
+        PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((nch + HG - 1) / HG), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0, 0x3Fu, 0u, nch));
+        PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(nch), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0x3Fu, 0u));
         if (nfr) PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((nfr + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, st, d_src, info, d.frames.as<DecFrame>(), nfr, d_dst, 0x3Fu));
     }
     HIP_TRY(hipGetLastError());

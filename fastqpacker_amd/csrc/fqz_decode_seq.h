@@ -81,11 +81,11 @@ __device__ __forceinline__ uint32_t seq_bits(const uint32_t *win, int wb, int lo
     return v & ((1u << n) - 1u);
 }
 
-__global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena)
+__global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena, uint32_t first)
 {
     __shared__ SeqFseLds T;
     __builtin_amdgcn_s_setprio(3); // a serial chain of short steps beside kernels that fill every issue slot: its waves go first
-    const uint32_t lane = threadIdx.x, g = lane >> 2, c = lane & 3, id = blockIdx.x * 16 + g;
+    const uint32_t lane = threadIdx.x, g = lane >> 2, c = lane & 3, id = first + blockIdx.x * 16 + g; // (chunks from `first` on: not the qualities)
     if (info->status) return;
     DecChunk ch;
     ch.seq_len = 0;
@@ -216,11 +216,11 @@ struct SeqExecLds {
 // it, as long as the compiler keeps the order
 #define SEQ_LDS_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-__global__ __launch_bounds__(64) void k_dec_seq_exec(DecInfo *info, const DecChunk *chunks, uint8_t *arena)
+__global__ __launch_bounds__(64) void k_dec_seq_exec(DecInfo *info, const DecChunk *chunks, uint8_t *arena, uint32_t first)
 {
     __shared__ __attribute__((aligned(16))) SeqExecLds S;
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t lane = threadIdx.x, id = blockIdx.x;
+    const uint32_t lane = threadIdx.x, id = first + blockIdx.x;
     if (id >= info->n_chunks || info->status) return;
     const DecChunk c = chunks[id];
     if (!c.seq_len) return;
