@@ -1528,7 +1528,13 @@ __global__ __launch_bounds__(256) void k_dec_check(DecInfo *info, const DecBlock
 // a record that continues from the previous round takes the running sum carried over instead.
 // ---------------------------------------------------------------------------
 #ifndef ASM_G
-#define ASM_G 64u // records a wave assembles at a time (<= 64)
+#define ASM_G 16u // records a wave assembles at a time (<= 64)
+#endif
+// The text of a trip's records is staged in LDS and leaves in aligned 16-byte units, whole lines at a time: a field of a
+// record is a run of ~150 bytes, and stored field by field its two end chunks were written to memory twice (WRITE_SIZE
+// 1.57 x the text).  Trips whose text does not fit the window (long reads) store directly as before.
+#ifndef ASM_W
+#define ASM_W 8192u // bytes of text a wave stages (0: never)
 #endif
 #define DRL(v, i) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (i)))
 #define DSH(v, i) ((uint32_t)__shfl((int)(v), (int)(i), WAVE))
@@ -1536,10 +1542,13 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
                                                       const uint32_t *__restrict__ offs, uint32_t ostride, const uint32_t *__restrict__ cols,
                                                       uint32_t cstride, uint32_t qoff, uint8_t *__restrict__ out)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][ASM_W + 32];
     if (info->status) return;
     const uint32_t n_rec = info->n_rec, nb = info->n_blocks;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
     const uint32_t n_groups = (n_rec + ASM_G - 1) / ASM_G;
+    uint8_t *const stg = s_stage[threadIdx.x >> 6];
+    const bool out_aligned = (((uintptr_t)out) & 15) == 0;
     for (uint32_t g = wave; g < n_groups; g += nwaves) {
         const uint32_t r = lane < ASM_G ? g * ASM_G + lane : n_rec;
         uint32_t m_L = 0, m_hdr = 0, m_H = 0, m_seq = 0, m_np = 0, m_nn = 0, m_plus = 0, m_P = 0, m_q = 0;
@@ -1558,6 +1567,11 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
             m_q = b->a_off[S_QUAL] + (cols[cstride + r] - cols[cstride + r0]);
         }
         const uint32_t o32 = (uint32_t)m_out; // a batch decodes to < 4 GiB (checked on the host before the launch)
+        // the trip's text is [o_lo, o_hi); staged: LDS byte (x - bias) holds output byte x
+        const uint32_t r_next = g * ASM_G + ASM_G < n_rec ? g * ASM_G + ASM_G : n_rec;
+        const uint32_t o_lo = DRL(o32, 0), o_hi = cols[2 * (size_t)cstride + r_next], bias = o_lo & ~15u;
+        const bool staged = ASM_W && out_aligned && o_hi - bias <= ASM_W;
+#define ASM_PUT(X, W4, NB) do { if (staged) store_piece(stg + ((X) - bias), (W4), (NB)); else store_piece(out + (X), (W4), (NB)); } while (0)
         const uint32_t pq = (m_L + 15) >> 4, ph = (m_H + 15) >> 4, pp = (m_P + 15) >> 4;
         const uint32_t iq = wave_incl_scan(pq), ih = wave_incl_scan(ph), ip = wave_incl_scan(pp);
         const PieceMap pm_iq = piece_map_make(pq, iq), pm_ih = piece_map_make(ph, ih), pm_ip = piece_map_make(pp, ip);
@@ -1587,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
                 for (uint32_t u = 0; u < 2; u++) {
                     if (base + u * WAVE < T && on[u]) {
                         const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                        store_piece(out + d[u], x, nb[u]);
+                        ASM_PUT(d[u], x, nb[u]);
                     }
                 }
             }
@@ -1656,8 +1670,8 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
             // second round's loads behind the first round's stores would wait for those too)
             auto commit = [&](PieceJob &J) {
                 if (J.on) {
-                    store_piece(out + J.dseq, J.xs, J.nbytes);
-                    store_piece(out + J.dq, J.xq, J.nbytes);
+                    ASM_PUT(J.dseq, J.xs, J.nbytes);
+                    ASM_PUT(J.dq, J.xq, J.nbytes);
                 }
             };
             for (uint32_t base = 0; base < Tq; base += 2 * WAVE) {
@@ -1675,14 +1689,31 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
         // Last, when the lines around them have just been written and are still in L2: stored first (before the pieces),
         // each of these single bytes sent a 128-byte line to HBM on its own (WRITE_SIZE 1.75 x the text).
         if (r < n_rec) {
-            uint8_t *o = out + m_out;
-            o[0] = '@';
-            o[1 + m_H] = '\n';
-            o[2 + m_H + m_L] = '\n';
-            o[3 + m_H + m_L] = '+';
-            o[4 + m_H + m_L + m_P] = '\n';
-            o[5 + m_H + 2 * m_L + m_P] = '\n';
+            if (staged) { // (the same six stores; spelled out twice so that each side keeps its address space)
+                uint8_t *q = stg + (o32 - bias);
+                q[0] = '@'; q[1 + m_H] = '\n'; q[2 + m_H + m_L] = '\n'; q[3 + m_H + m_L] = '+'; q[4 + m_H + m_L + m_P] = '\n'; q[5 + m_H + 2 * m_L + m_P] = '\n';
+            } else {
+                uint8_t *o = out + m_out;
+                o[0] = '@';
+                o[1 + m_H] = '\n';
+                o[2 + m_H + m_L] = '\n';
+                o[3 + m_H + m_L] = '+';
+                o[4 + m_H + m_L + m_P] = '\n';
+                o[5 + m_H + 2 * m_L + m_P] = '\n';
+            }
         }
+        if (staged) { // the window leaves: the bytes in front of the first aligned unit, whole 16-byte units, the bytes behind the last
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t a_lo = (o_lo + 15) & ~15u, a_hi = o_hi & ~15u;
+            const uint32_t head_end = a_lo < o_hi ? a_lo : o_hi;
+            if (lane < head_end - o_lo) out[o_lo + lane] = stg[o_lo - bias + lane];
+            for (uint32_t i = a_lo + 16 * lane; i < a_hi; i += 16 * WAVE) *(uint4 *)(out + i) = *(const uint4 *)(stg + (i - bias));
+            if (a_hi >= a_lo && lane < o_hi - a_hi) out[a_hi + lane] = stg[a_hi - bias + lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+#undef ASM_PUT
         // ---- N overlay (rare): after the bases of this group are stored
         unsigned long long todo = __ballot(m_nn != 0);
         if (todo) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
