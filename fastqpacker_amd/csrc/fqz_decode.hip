@@ -1528,13 +1528,13 @@ __global__ __launch_bounds__(256) void k_dec_check(DecInfo *info, const DecBlock
 // a record that continues from the previous round takes the running sum carried over instead.
 // ---------------------------------------------------------------------------
 #ifndef ASM_G
-#define ASM_G 16u // records a wave assembles at a time (<= 64)
+#define ASM_G 64u // records a wave gathers the metadata of at a time (<= 64)
 #endif
 // The text of a trip's records is staged in LDS and leaves in aligned 16-byte units, whole lines at a time: a field of a
 // record is a run of ~150 bytes, and stored field by field its two end chunks were written to memory twice (WRITE_SIZE
 // 1.57 x the text).  Trips whose text does not fit the window (long reads) store directly as before.
 #ifndef ASM_W
-#define ASM_W 8192u // bytes of text a wave stages (0: never)
+#define ASM_W 12288u // bytes of text a wave stages (0: never); 34 records of 150 bp
 #endif
 #define DRL(v, i) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (i)))
 #define DSH(v, i) ((uint32_t)__shfl((int)(v), (int)(i), WAVE))
@@ -1567,12 +1567,23 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
             m_q = b->a_off[S_QUAL] + (cols[cstride + r] - cols[cstride + r0]);
         }
         const uint32_t o32 = (uint32_t)m_out; // a batch decodes to < 4 GiB (checked on the host before the launch)
-        // the trip's text is [o_lo, o_hi); staged: LDS byte (x - bias) holds output byte x
-        const uint32_t r_next = g * ASM_G + ASM_G < n_rec ? g * ASM_G + ASM_G : n_rec;
-        const uint32_t o_lo = DRL(o32, 0), o_hi = cols[2 * (size_t)cstride + r_next], bias = o_lo & ~15u;
-        const bool staged = ASM_W && out_aligned && o_hi - bias <= ASM_W;
+        const uint32_t rec_end = o32 + (r < n_rec ? m_H + m_P + 2 * m_L + 6 : 0u);
+        const uint32_t n_here = n_rec - g * ASM_G < ASM_G ? n_rec - g * ASM_G : ASM_G;
+        // trips over the group's records: as many consecutive records as the staging window holds (one that does not fit alone
+        // - a long read - is stored directly, as every record used to be)
+        for (uint32_t lo = 0; lo < n_here;) {
+        const uint32_t o_lo = (uint32_t)__builtin_amdgcn_readlane((int)o32, (int)lo), bias = o_lo & ~15u;
+        const unsigned long long fits = __ballot(lane >= lo && lane < n_here && rec_end - bias <= ASM_W);
+        const unsigned long long stop = ~fits & (~0ull << lo);
+        uint32_t hi = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+        hi = hi < n_here ? hi : n_here;
+        const bool staged = ASM_W && out_aligned && hi > lo;
+        if (!(ASM_W && out_aligned)) hi = n_here; // (no staging at all: the whole group in one trip)
+        else if (hi == lo) hi = lo + 1;
+        const uint32_t o_hi = (uint32_t)__builtin_amdgcn_readlane((int)rec_end, (int)(hi - 1));
+        const bool in = lane >= lo && lane < hi; // this lane's record belongs to the trip
 #define ASM_PUT(X, W4, NB) do { if (staged) store_piece(stg + ((X) - bias), (W4), (NB)); else store_piece(out + (X), (W4), (NB)); } while (0)
-        const uint32_t pq = (m_L + 15) >> 4, ph = (m_H + 15) >> 4, pp = (m_P + 15) >> 4;
+        const uint32_t pq = in ? (m_L + 15) >> 4 : 0u, ph = in ? (m_H + 15) >> 4 : 0u, pp = in ? (m_P + 15) >> 4 : 0u;
         const uint32_t iq = wave_incl_scan(pq), ih = wave_incl_scan(ph), ip = wave_incl_scan(pp);
         const PieceMap pm_iq = piece_map_make(pq, iq), pm_ih = piece_map_make(ph, ih), pm_ip = piece_map_make(pp, ip);
         const uint32_t Tq = DRL(iq, 63), Th = DRL(ih, 63), Tp = DRL(ip, 63);
@@ -1688,7 +1699,7 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
         // ---- the fixed bytes of the record: '@', the three '\n' after header / sequence / plus, '+', the final '\n'.
         // Last, when the lines around them have just been written and are still in L2: stored first (before the pieces),
         // each of these single bytes sent a 128-byte line to HBM on its own (WRITE_SIZE 1.75 x the text).
-        if (r < n_rec) {
+        if (r < n_rec && in) {
             if (staged) { // (the same six stores; spelled out twice so that each side keeps its address space)
                 uint8_t *q = stg + (o32 - bias);
                 q[0] = '@'; q[1 + m_H] = '\n'; q[2 + m_H + m_L] = '\n'; q[3 + m_H + m_L] = '+'; q[4 + m_H + m_L + m_P] = '\n'; q[5 + m_H + 2 * m_L + m_P] = '\n';
@@ -1713,9 +1724,8 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-#undef ASM_PUT
         // ---- N overlay (rare): after the bases of this group are stored
-        unsigned long long todo = __ballot(m_nn != 0);
+        unsigned long long todo = __ballot(in && m_nn != 0);
         if (todo) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         while (todo) {
             const int i = __ffsll((long long)todo) - 1;
@@ -1728,6 +1738,9 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
                 if (pz >= L) dec_fail(info, FQZ_E_NPOS_RANGE); else os[pz] = 'N';
             }
         }
+        lo = hi;
+        } // trips
+#undef ASM_PUT
     }
 }
 
