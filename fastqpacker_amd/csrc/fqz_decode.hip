@@ -1534,7 +1534,7 @@ __global__ __launch_bounds__(256) void k_dec_check(DecInfo *info, const DecBlock
 // record is a run of ~150 bytes, and stored field by field its two end chunks were written to memory twice (WRITE_SIZE
 // 1.57 x the text).  Trips whose text does not fit the window (long reads) store directly as before.
 #ifndef ASM_W
-#define ASM_W 12288u // bytes of text a wave stages (0: never); 34 records of 150 bp
+#define ASM_W 8192u // bytes of text a wave stages (0: never); 23 records of 150 bp (A/B on one box: 4 KiB 0.56 ms, 6 KiB 0.53, 8 KiB 0.50, 12 KiB 0.53, 16 KiB 0.65; direct stores 0.76-0.86)
 #endif
 #define DRL(v, i) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (i)))
 #define DSH(v, i) ((uint32_t)__shfl((int)(v), (int)(i), WAVE))
