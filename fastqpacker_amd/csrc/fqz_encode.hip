@@ -669,11 +669,12 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
             d_plus = p->a_off[S_PLUS] + (ep - Eplus[r0]);
             // ---- length: u32 L (one coalesced store per lane); record prefixes: u16 H, u16 P (compress.go:509-519)
             *(uint32_t *)(arena + p->a_off[S_LEN] + 4 * (r - r0)) = L;
-            uint8_t *dh = arena + d_hdr, *dp = arena + d_plus;
-            dh[0] = (uint8_t)H; dh[1] = (uint8_t)(H >> 8);
-            dp[0] = (uint8_t)P; dp[1] = (uint8_t)(P >> 8);
+            // (the header's u16 travels with its first piece below: a store of its own wrote the same memory chunk twice;
+            //  the plus line's - nearly always bare - in one 2-byte store)
+            const uint16_t p16 = (uint16_t)P;
+            __builtin_memcpy(arena + d_plus, &p16, 2);
         }
-        const uint32_t pq = (L + 15) >> 4, ph = (H + 15) >> 4, pp = (P + 15) >> 4;
+        const uint32_t pq = (L + 15) >> 4, ph = r < n_rec ? (H + 2 + 15) >> 4 : 0u, pp = (P + 15) >> 4; // header pieces cover [u16 H][payload]
         const uint32_t iq = wave_incl_scan(pq), ih = wave_incl_scan(ph), ip = wave_incl_scan(pp);
         const PieceMap pm_iq = piece_map_make(pq, iq), pm_ih = piece_map_make(ph, ih), pm_ip = piece_map_make(pp, ip);
         const uint32_t Tq = (uint32_t)RL(iq, 63), Th = (uint32_t)RL(ih, 63), Tp = (uint32_t)RL(ip, 63);
@@ -768,10 +769,15 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
             piece_locate(pm_ih, ih, ph, on ? p : 0, &i, &k);
             const uint32_t Hi = (uint32_t)__shfl((int)H, (int)i, WAVE), src = (uint32_t)__shfl((int)s_hdr, (int)i, WAVE);
             const uint32_t dst = (uint32_t)__shfl((int)d_hdr, (int)i, WAVE);
-            if (on) {
+            if (on) { // piece k = bytes [16 k, 16 k + 16) of the record's image [u16 H][H payload bytes]
                 uint32_t x[4];
-                load_piece(text, src + 16 * k, n_text, x);
-                store_piece(arena + dst + 2 + 16 * k, x, Hi - 16 * k < 16 ? Hi - 16 * k : 16);
+                if (k) load_piece(text, src + 16 * k - 2, n_text, x);
+                else {
+                    uint32_t y[4];
+                    load_piece(text, src, n_text, y);
+                    x[0] = (y[0] << 16) | (Hi & 0xFFFFu); x[1] = (y[1] << 16) | (y[0] >> 16); x[2] = (y[2] << 16) | (y[1] >> 16); x[3] = (y[3] << 16) | (y[2] >> 16);
+                }
+                store_piece(arena + dst + 16 * k, x, Hi + 2 - 16 * k < 16 ? Hi + 2 - 16 * k : 16);
             }
         }
         for (uint32_t base = 0; base < Tp; base += WAVE) {
