@@ -114,6 +114,7 @@ SIGNATURES = {
     "fqz_decompress_alloc": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(DecompressOptions)]),
     "fqz_buffer_free": (None, [_vp]),
     "fqz_compress_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Options)]),
+    "fqz_decompress_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, _vp, C.c_size_t, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(DecompressOptions)]),
     "fqz_compress_file": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.POINTER(Options)]),
     "fqz_decompress_file": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.POINTER(DecompressOptions)]),
     "fqz_profile_enable": (C.c_int, [_vp, C.c_int]),

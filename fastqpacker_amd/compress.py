@@ -41,6 +41,21 @@ def CompressMulti(fastq, devices, opts: Options = None) -> bytes:
     return out[: n.value].tobytes()
 
 
+def DecompressMulti(fqz, devices, opts: DecompressOptions = None) -> bytes:
+    """compress.Decompress with the reference's worker pool spread over several devices (compress.go:630-668): contiguous
+    ranges of whole blocks per device, texts concatenated in order; identical to Decompress."""
+    a = _as_u8(fqz)
+    n = C.c_size_t(0)
+    p = C.c_void_p()
+    devs = (C.c_int * len(devices))(*devices)
+    check(lib().fqz_decompress_multi(devs, len(devices), a.ctypes.data if a.size else None, a.size, C.byref(p), C.byref(n),
+                                     C.byref(opts) if opts is not None else None))
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        lib().fqz_buffer_free(p)
+
+
 def Decompress(fqz, opts: DecompressOptions = None, ctx=None) -> bytes:
     """compress.Decompress (compress.go:558): .fqz bytes -> FASTQ bytes (one decode; the library allocates the text)."""
     ctx = ctx or default_ctx()

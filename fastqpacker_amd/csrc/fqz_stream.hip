@@ -270,18 +270,22 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts, const Sha
 // ===========================================================================
 // compress.Decompress
 // ===========================================================================
-static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *opts)
+// body_of: the source starts at a block header and belongs to a file with this header (a shard of fqz_decompress_multi)
+static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *opts, const fqz_file_header *body_of = nullptr)
 {
     (void)opts;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = ensure_lanes(ctx);
     if (rc) return rc;
-    uint8_t hdr[FQZ_FILE_HEADER_SIZE];
-    long got = io.read_full(hdr, FQZ_FILE_HEADER_SIZE);
-    if (got < 0) return (int)got;
     fqz_file_header fh;
-    rc = fqz_read_file_header(hdr, (size_t)got, &fh);                   // compress.go:567-570
-    if (rc) return rc;
+    if (body_of) fh = *body_of;
+    else {
+        uint8_t hdr[FQZ_FILE_HEADER_SIZE];
+        long got = io.read_full(hdr, FQZ_FILE_HEADER_SIZE);
+        if (got < 0) return (int)got;
+        rc = fqz_read_file_header(hdr, (size_t)got, &fh);               // compress.go:567-570
+        if (rc) return rc;
+    }
     if (fh.version != FQZ_VERSION1 && fh.version != FQZ_VERSION2) return FQZ_E_FILE_VERSION; // compress.go:571-573
     const int enc = (fh.flags & FQZ_FLAG_PHRED64) ? FQZ_ENCODING_PHRED64 : FQZ_ENCODING_PHRED33; // compress.go:576-579
     Pipe P(ctx);
@@ -688,5 +692,73 @@ extern "C" int fqz_compress_multi(const int *devices, int n_devices, const uint8
     size_t pos = 0;
     for (int d = 0; d < N; d++) { if (!sh[d].out.empty()) memcpy(out + pos, sh[d].out.data(), sh[d].out.size()); pos += sh[d].out.size(); }
     *out_len = total;
+    return FQZ_OK;
+}
+
+// compress.Decompress over several devices: the block headers are walked on the host (readNextDecompressJob,
+// compress.go:721-758), every device takes a contiguous range of whole blocks of about the same compressed size through the
+// streaming pipeline above, and the texts are concatenated in order.  Byte-identical to fqz_decompress on one device.
+extern "C" int fqz_decompress_multi(const int *devices, int n_devices, const uint8_t *fqz, size_t n, uint8_t **out, size_t *out_len,
+                                    const fqz_decompress_options *opts)
+{
+    if (!devices || n_devices < 1 || n_devices > 64 || !fqz || !out || !out_len) return FQZ_E_ARG;
+    *out = nullptr; *out_len = 0;
+    fqz_file_header fh;
+    int rc = fqz_read_file_header(fqz, n, &fh);
+    if (rc) return rc;
+    if (fh.version != FQZ_VERSION1 && fh.version != FQZ_VERSION2) return FQZ_E_FILE_VERSION;
+    // block boundaries
+    std::vector<size_t> starts;
+    size_t pos = FQZ_FILE_HEADER_SIZE;
+    while (pos < n) {
+        fqz_block_header bh;
+        const int h = fqz_read_block_header(fqz + pos, n - pos, fh.version, &bh);
+        if (h < 0) return h;
+        const unsigned long long pay = (unsigned long long)bh.seq_size + bh.qual_size + bh.header_size + bh.plus_size + bh.npos_size + bh.lengths_size;
+        if (pay > n - pos - (size_t)h) return FQZ_E_READ_DATA;
+        starts.push_back(pos);
+        pos += (size_t)h + (size_t)pay;
+    }
+    starts.push_back(n);
+    const size_t nblk = starts.size() - 1;
+    const int N = n_devices;
+    struct DShard { size_t a = 0, b = 0; fqz_ctx *ctx = nullptr; std::vector<uint8_t> out; int rc = 0; };
+    std::vector<DShard> sh((size_t)N);
+    { // contiguous ranges of whole blocks: a device takes the blocks that end at or before its share of the compressed bytes
+      // (none, when a block is larger than a share), the last device the rest
+        size_t k = 0;
+        for (int d = 0; d < N; d++) {
+            sh[d].a = starts[k];
+            if (d + 1 == N) k = nblk;
+            else {
+                const size_t want = FQZ_FILE_HEADER_SIZE + (size_t)((unsigned long long)(n - FQZ_FILE_HEADER_SIZE) * (unsigned)(d + 1) / (unsigned)N);
+                while (k < nblk && starts[k + 1] <= want) k++;
+            }
+            sh[d].b = starts[k];
+        }
+    }
+    std::vector<std::thread> th;
+    for (int d = 0; d < N; d++)
+        th.emplace_back([&, d] {
+            DShard &s = sh[d];
+            if (s.a >= s.b) return;
+            if (hipSetDevice(devices[d]) != hipSuccess) { s.rc = FQZ_E_HIP; return; }
+            if ((s.rc = fqz_ctx_create(devices[d], &s.ctx))) return;
+            Io io;
+            io.mem_in = fqz + s.a; io.mem_in_n = s.b - s.a;
+            io.wr = grow_vec; io.wr_user = &s.out;
+            s.rc = decompress_job(s.ctx, io, opts, &fh);
+        });
+    for (auto &t : th) t.join();
+    for (int d = 0; d < N; d++)
+        if (sh[d].ctx) { (void)hipSetDevice(devices[d]); fqz_ctx_destroy(sh[d].ctx); }
+    for (int d = 0; d < N; d++) if (sh[d].rc) return sh[d].rc; // the error of the earliest shard
+    size_t total = 0;
+    for (int d = 0; d < N; d++) total += sh[d].out.size();
+    uint8_t *buf = (uint8_t *)malloc(total ? total : 1);
+    if (!buf) return FQZ_E_NOMEM;
+    size_t at = 0;
+    for (int d = 0; d < N; d++) { if (!sh[d].out.empty()) memcpy(buf + at, sh[d].out.data(), sh[d].out.size()); at += sh[d].out.size(); }
+    *out = buf; *out_len = total;
     return FQZ_OK;
 }

@@ -236,6 +236,11 @@ void fqz_buffer_free(uint8_t *p);
  * range of whole 100 000-record blocks; the output is byte-identical to fqz_compress on one device. */
 int fqz_compress_multi(const int *devices, int n_devices, const uint8_t *fastq, size_t n, uint8_t *out, size_t out_cap, size_t *out_len,
                        const fqz_options *opts);
+/* compress.Decompress over several devices (readNextDecompressJob + worker pool + ordered writer, compress.go:630-758): the
+ * block headers are walked on the host, every device decodes a contiguous range of whole blocks, the texts are concatenated
+ * in order.  The library allocates *out (release it with fqz_buffer_free); identical to fqz_decompress_alloc. */
+int fqz_decompress_multi(const int *devices, int n_devices, const uint8_t *fqz, size_t n, uint8_t **out, size_t *out_len,
+                         const fqz_decompress_options *opts);
 /* File-to-file forms used by the fqpack CLI driver (cmd/fqpack/main.go:190-203); stream through the same pipeline. */
 int fqz_compress_file(fqz_ctx *ctx, const char *in_path, const char *out_path, const fqz_options *opts);
 int fqz_decompress_file(fqz_ctx *ctx, const char *in_path, const char *out_path, const fqz_decompress_options *opts);

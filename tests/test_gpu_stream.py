@@ -142,11 +142,17 @@ def test_compress_multi_is_identical_to_one_device(fq):
     small = small[: small.rfind(b"\n@") + 1]
     assert fq.compress.CompressMulti(small, [0, 0]) == fq.compress.Compress(small)
     assert fq.compress.CompressMulti(b"", [0, 0]) == fq.compress.Compress(b"")
+    for devs in ([0], [0, 0], [0, 0, 0], [0] * 7):                                    # the way back: ranges of whole blocks per device
+        assert fq.compress.DecompressMulti(want, devs) == text, devs
+    assert fq.compress.DecompressMulti(fq.compress.Compress(b""), [0, 0]) == b""
+    with pytest.raises(Exception):
+        fq.compress.DecompressMulti(want[:-5], [0, 0])                                  # "reading block data: unexpected EOF"
     # Phred+64 decided by the first shard, applied by the others
     t64, _ = fq.compress.synth_fastq(250_000, min_len=40, max_len=60, phred=64)
     t64 = t64.tobytes()
     w64 = fq.compress.Compress(t64)
     assert w64[9] & 2 and fq.compress.CompressMulti(t64, [0, 0]) == w64
+    assert fq.compress.DecompressMulti(w64, [0, 0]) == t64
     # a parse error in a later shard is reported
     bad = bytearray(text)
     at = text.rfind(b"\n+\n")
