@@ -84,6 +84,7 @@ struct EncState {
     DevBuf scan_state; // look-back states of k_scan + its ticket
     DevBuf gmap;      // chunk-group descriptors (k_group_map)
     DevBuf hside;     // headers model: sequences | literals | Sequences_Sections | HdrSide | chunk list (fqz_hdrlz.h)
+    uint32_t plans_pre = 0;           // block plans already copied to the host with the counters (fqz_enc_launch)
     uint32_t hcap = 0, hcap_need = 0; // headers chunks the side buffers hold / the last batch needed
     double hcap_per_mb = 0;           // headers chunks per MiB of text of the last batch that overflowed the optimistic size
     DevBuf xmap;      // descriptors of every group (frame) for the content checksums | xsum[chunk_cap]

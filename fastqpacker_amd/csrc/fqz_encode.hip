@@ -1412,6 +1412,9 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, xsum, arena, d_out, (uint32_t)S_SEQ));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
+    // (the plans of the first blocks travel with the counters: a caller that asks for block offsets needs no second round trip)
+    e.plans_pre = e.block_cap < 256 ? e.block_cap : 256;
+    HIP_TRY(hipMemcpyAsync(e.h_plans.p, plans, sizeof(BlockPlan) * (size_t)e.plans_pre, hipMemcpyDeviceToHost, st));
     e.in_flight = true;
     return FQZ_OK;
 }
@@ -1454,8 +1457,10 @@ int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uin
     if (hi->status) return hi->status;
     if ((block_off || block_len) && hi->n_blocks) {
         if (hi->n_blocks > max_blocks) return FQZ_E_DST_SMALL;
-        HIP_TRY(hipMemcpyAsync(e.h_plans.p, e.plans.p, sizeof(BlockPlan) * (size_t)hi->n_blocks, hipMemcpyDeviceToHost, e.stream));
-        HIP_TRY(hipStreamSynchronize(e.stream));
+        if (hi->n_blocks > e.plans_pre) {
+            HIP_TRY(hipMemcpyAsync(e.h_plans.p, e.plans.p, sizeof(BlockPlan) * (size_t)hi->n_blocks, hipMemcpyDeviceToHost, e.stream));
+            HIP_TRY(hipStreamSynchronize(e.stream));
+        }
         const BlockPlan *hp = e.h_plans.as<BlockPlan>();
         for (uint32_t b = 0; b < hi->n_blocks; b++) {
             if (block_off) block_off[b] = hp[b].out_off;
