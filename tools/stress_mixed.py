@@ -1,0 +1,29 @@
+"""One-off: records of wildly mixed lengths (20 bp .. 40 kbp, with N, with plus payloads) through Compress / Decompress:
+the staged text assembly takes as many records per trip as fit its window and stores oversized ones directly."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch  # noqa: F401
+import fastqpacker_amd as fq
+import oracle_lib as O
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
+bad = 0
+for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
+    recs = []
+    n = int(rng.integers(50, 3000))
+    for i in range(n):
+        kind = rng.random()
+        L = int(rng.integers(20, 300)) if kind < 0.9 else (int(rng.integers(2000, 9000)) if kind < 0.98 else int(rng.integers(9000, 40000)))
+        seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), L, p=[.245, .245, .245, .245, .02]).tobytes()
+        q = rng.integers(35, 74, L, dtype=np.uint8).tobytes()
+        h = b"r%d/%d len=%d" % (case, i, L)
+        plus = h if rng.random() < 0.2 else b""
+        recs.append(b"@" + h + b"\n" + seq + b"\n+" + plus + b"\n" + q + b"\n")
+    text = b"".join(recs)
+    z = fq.compress.Compress(text)
+    ok = z == O.compress(text) and fq.compress.Decompress(z) == text and O.decompress(z) == text
+    print("case %d: %d records, %d bytes -> %d: %s" % (case, n, len(text), len(z), "ok" if ok else "FAIL"), flush=True)
+    bad += not ok
+sys.exit(1 if bad else 0)
