@@ -10,6 +10,7 @@ ENCODING_PHRED33 = 0
 ENCODING_PHRED64 = 1
 DETECT_ENCODING = -1
 BATCH_FINAL = 1
+BATCH_V3 = 2
 DEFAULT_BLOCK_SIZE = 100000
 STREAM_NAMES = ["seq", "qual", "headers", "plus", "npos", "lengths"]
 
@@ -30,8 +31,9 @@ class BatchResult(C.Structure):
 
 
 class Options(C.Structure):
-    """compress.Options (compress.go:74-77)."""
-    _fields_ = [("block_size", C.c_uint32), ("workers", C.c_int32)]
+    """compress.Options (compress.go:74-77) + container_version (0 / 2: the reference's CurrentVersion; 3: FQZ-R1, rANS-coded
+    qualities - SURVEY 8 f-4, not readable by the stock decoder)."""
+    _fields_ = [("block_size", C.c_uint32), ("workers", C.c_int32), ("container_version", C.c_uint32)]
 
 
 class DecompressOptions(C.Structure):

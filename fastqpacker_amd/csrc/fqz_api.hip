@@ -152,7 +152,7 @@ extern "C" int fqz_write_block_header(const fqz_block_header *b, uint8_t version
         for (int i = 0; i < 8; i++) put32(out + 4 * i, v[i]);
         return 32;
     }
-    if (version == FQZ_VERSION2) {
+    if (version == FQZ_VERSION2 || version == FQZ_VERSION3) {
         const uint32_t v[9] = {b->num_records, b->seq_size, b->qual_size, b->header_size, b->plus_size, b->npos_size,
                                b->lengths_size, b->original_seq_size, b->original_qual_size};
         for (int i = 0; i < 9; i++) put32(out + 4 * i, v[i]);
@@ -171,7 +171,7 @@ extern "C" int fqz_read_block_header(const uint8_t *in, size_t n, uint8_t versio
         b->original_qual_size = get32(in + 28);
         return 32;
     }
-    if (version == FQZ_VERSION2) {
+    if (version == FQZ_VERSION2 || version == FQZ_VERSION3) {
         if (n < 36) return FQZ_E_SHORT;
         b->num_records = get32(in); b->seq_size = get32(in + 4); b->qual_size = get32(in + 8); b->header_size = get32(in + 12);
         b->plus_size = get32(in + 16); b->npos_size = get32(in + 20); b->lengths_size = get32(in + 24);

@@ -686,7 +686,7 @@ __global__ __launch_bounds__(64) void k_dec_lz(const uint8_t *in, DecInfo *info,
 // type and finds the Huffman tree a treeless block refers to (an earlier block of its group).  Anything that does not
 // add up sends the batch down the general path (the index is a hint, never trusted).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_dec_index(const uint8_t *in, DecInfo *info, const DecBlock *blocks, DecChunk *chunks, DecFrame *frames)
+__global__ __launch_bounds__(256) void k_dec_index(const uint8_t *in, DecInfo *info, const DecBlock *blocks, DecChunk *chunks, DecFrame *frames, uint2 *rlist, uint32_t rcap)
 {
     __shared__ uint32_t sh[4];
     const uint32_t id = blockIdx.x, t = threadIdx.x;
@@ -724,7 +724,29 @@ __global__ __launch_bounds__(256) void k_dec_index(const uint8_t *in, DecInfo *i
                 d.src_off = pos + 3; d.csize = csize; d.dst_off = b->a_off[s] + c * FQZ_CHUNK; d.regen = mk; d.btype = type;
                 d.tree_off = 0; d.tree_len = 0; d.stream = (uint32_t)s;
                 d.seq_len = 0; d.out_off = d.dst_off; d.out_len = mk;
-                if (type == 3 || 3 + csize != sz || last != (last_in_group ? 1u : 0u)) bad = true;
+                if (3 + csize != sz || last != (last_in_group ? 1u : 0u)) bad = true;
+                else if (type == 3) {
+                    // FQZ-R1 (version-3 files, fqz_rans.h): m u16 | tflag | [table] | words | 16 states.  The first such block of a
+                    // group carries the table (and announces the group to k_dec_rans), the others must find it in front of them
+                    if (!rlist || s != S_QUAL || bs < 3 + 64 || rd16(q + 3) != mk || (q[5] & ~1u)) bad = true;
+                    else {
+                        d.btype = 4;
+                        bool first = true; // no type-3 block of this group in front of this one
+                        uint32_t back = 0;
+                        for (uint32_t j = 1; j <= cg && !bad; j++) {
+                            back += rd24(idx + 3 * (c - j));
+                            if (back > pos - body0) { bad = true; break; }
+                            if (((rd24(in + pos - back) >> 1) & 3) == 3) first = false;
+                        }
+                        if (first != ((q[5] & 1u) != 0)) bad = true;
+                        else if (first) {
+                            const uint32_t r = atomicAdd(&info->n_rgroups, 1u);
+                            const uint32_t in_group = nch - (c - cg) < FQZ_GROUP ? nch - (c - cg) : FQZ_GROUP;
+                            if (r < rcap) rlist[r] = make_uint2(b->chunk_base[s] + c - cg, in_group | (cg << 8));
+                            else bad = true;
+                        }
+                    }
+                }
                 else if (type != 2) { if (bs != mk) bad = true; }
                 else {
                     // Compressed block: literals only (Number_of_Sequences = 0), regenerating exactly the chunk
@@ -853,6 +875,8 @@ __device__ __forceinline__ int bbp_init(BackBitsP &b, const uint8_t *p, uint32_t
 }
 
 #include "fqz_decode_seq.h"
+#define FQZ_RANS_DECODER
+#include "fqz_rans.h"
 
 #define HG 16           // blocks per wave
 #define L1_BITS 8
@@ -1086,6 +1110,16 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
     if (ok && sub == 0 && !fail) chunks[id].btype = 3; // done: the general kernel skips it
 }
 
+// FQZ-R1 blocks (version-3 files): a wave per group that k_dec_index listed (fqz_rans.h)
+__global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *in, DecInfo *info, const DecChunk *chunks, const uint2 *rlist, uint32_t rcap, uint8_t *arena)
+{
+    __shared__ __attribute__((aligned(16))) RansDecLds S;
+    if (blockIdx.x >= info->n_rgroups || blockIdx.x >= rcap || info->status) return;
+    bool failed = false;
+    rans_decode_group(S, in, chunks, rlist[blockIdx.x], arena, &failed);
+    if (failed) dec_fail(info, FQZ_E_ENTROPY);
+}
+
 __global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena, uint32_t stream_mask, uint32_t first)
 {
     __shared__ uint16_t s_dt[4096];
@@ -1095,7 +1129,7 @@ __global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *
     const uint32_t id = first + blockIdx.x;
     if (id >= info->n_chunks || info->status) return;
     const DecChunk c = chunks[id];
-    if (c.btype == 3 || !((stream_mask >> c.stream) & 1u)) return; // decoded by k_dec_huf / another launch's stream
+    if (c.btype >= 3 || !((stream_mask >> c.stream) & 1u)) return; // decoded by k_dec_huf (3) / k_dec_rans (4) / another launch's stream
     const uint8_t *src = in + c.src_off;
     uint8_t *dst = arena + c.dst_off;
     const uint32_t lane = threadIdx.x;
@@ -1814,7 +1848,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
 {
     DecState &d = ctx->dec;
     if (d.in_flight) return FQZ_E_ARG;
-    if (version != FQZ_VERSION1 && version != FQZ_VERSION2) return FQZ_E_BLOCK_VERSION;
+    if (version != FQZ_VERSION1 && version != FQZ_VERSION2 && version != FQZ_VERSION3) return FQZ_E_BLOCK_VERSION;
     if (n_bytes >= 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
     if ((uintptr_t)d_in & 15) return FQZ_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1960,8 +1994,9 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     if (n_lz && (rc = d.lz_scratch.ensure((size_t)n_lz * LZ_SCRATCH))) return rc;
     if ((rc = d.chunks.ensure(sizeof(DecChunk) * ((size_t)n_chunks + 1)))) return rc;
     const uint32_t n_frames = (uint32_t)nframes;
-    if ((rc = d.frames.ensure(sizeof(DecFrame) * ((size_t)n_frames + 1)))) return rc;
+    if ((rc = d.frames.ensure((sizeof(DecFrame) + sizeof(uint2)) * ((size_t)n_frames + 1)))) return rc; // frames | groups with rANS blocks
     DecFrame *dfr = d.frames.as<DecFrame>();
+    uint2 *rlist = version == FQZ_VERSION3 ? (uint2 *)(dfr + (size_t)n_frames + 1) : nullptr; // (version-3 files only: FQZ-R1, fqz_rans.h)
     if ((rc = d.rec.ensure(4ull * (3ull * ostride + 3ull * cstride) + 64))) return rc;
     uint32_t pmax = n_rec / DSCAN_TILE + 2;
     if ((rc = d.partials.ensure(4ull * 3 * pmax + 24ull * ((size_t)nb + 1)))) return rc;
@@ -1978,7 +2013,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     HIP_TRY(hipMemcpyAsync(&info->n_chunks, &hi->n_chunks, 4, hipMemcpyHostToDevice, st));
     // ---- bulk kernels
     PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, dch, dfr, general ? 1 : 2));
-    if (any_indexed) PROF(ctx, st, "k_dec_index", hipLaunchKernelGGL(k_dec_index, dim3(fgrid), dim3(256), 0, st, d_in, info, blocks, dch, dfr));
+    if (any_indexed) PROF(ctx, st, "k_dec_index", hipLaunchKernelGGL(k_dec_index, dim3(fgrid), dim3(256), 0, st, d_in, info, blocks, dch, dfr, rlist, n_frames));
     // The record walks and the size scans below need only the header / plus / nPos / lengths streams, the text assembly
     // at the end needs the bases and qualities too.  The latter are 3/4 of the entropy decode and the walks leave the
     // chip almost empty, so the two run side by side: bases + qualities on the context's side stream, joined before
@@ -2017,6 +2052,10 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             PROF(ctx, st, "k_dec_seq_exec", hipLaunchKernelGGL(k_dec_seq_exec, dim3(n_o), dim3(64), 0, st, info, dch, darena, n_q));
         }
         // (holding the qualities' decode back until the sequence bit streams are through measured 380 against 418 GB/s)
+        if (n_q && rlist) { // version 3: the qualities are rANS blocks, a wave per group (at most one group per frame)
+            const uint32_t rg = (n_q + FQZ_GROUP - 1) / FQZ_GROUP + nb < n_frames ? (n_q + FQZ_GROUP - 1) / FQZ_GROUP + nb : n_frames;
+            PROF(ctx, sd, "k_dec_rans", hipLaunchKernelGGL(k_dec_rans, dim3(rg ? rg : 1), dim3(64), 0, sd, d_in, info, dch, rlist, n_frames, darena));
+        }
         if (n_q) {
             PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_q + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late, 0u, n_q));
             PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_q), dim3(64), 0, sd, d_in, info, dch, darena, late, 0u));

@@ -16,6 +16,7 @@
 #include "fqz_entropy_dev.h"
 #include "fqz_xxh.h"
 #include "fqz_hdrlz.h"
+#include "fqz_rans.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -846,7 +847,7 @@ __device__ __forceinline__ uint32_t h2_frame_hdr(uint32_t M) { return M < 256u ?
 // are Raw blocks by definition: their "compressed" size is known here and k_compact copies them straight from the arena.
 // cinfo[chunk] = block | stream << 24, for k_compact (which would otherwise repeat the search, one dependent load after another)
 __global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPlan *plans, uint4 *gmap, uint4 *hmap, uint4 *xmap, uint32_t group_cap, uint32_t *cinfo, uint32_t *csize,
-                                                   uint32_t *hord, uint32_t *hlist, uint32_t hcap)
+                                                   uint32_t *hord, uint32_t *hlist, uint32_t hcap, uint4 *rmap)
 {
     const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
     if (chunk >= info->n_chunks) return;
@@ -873,6 +874,11 @@ __global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPla
         if (g < group_cap) hmap[g] = d;
         return;
     }
+    if (s == S_QUAL && rmap) { // container version 3: the qualities go to the rANS coder (fqz_rans.h)
+        const uint32_t g = atomicAdd(&info->n_rgroups, 1u);
+        if (g < group_cap) rmap[g] = d;
+        return;
+    }
     const uint32_t g = atomicAdd(&info->n_groups, 1u);
     if (g < group_cap) gmap[g] = d;
 }
@@ -887,6 +893,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (stamps) { stamps += (size_t)chunk * 16; if (threadIdx.x == 0) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[15] = (unsigned long long)s; } }
     const uint8_t *src = (s == S_NPOS ? npos_arena : arena) + gd.y; // 16-byte aligned
     entropy_encode_group<false>(S, src, M, 0u, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg_stop, stamps);
+}
+
+// Container version 3 (FQZ-R1): the groups of the quality streams, a wave each (fqz_rans.h)
+__global__ __launch_bounds__(64) void k_rans(const EncInfo *info, const uint4 *rmap, const uint8_t *arena, uint8_t *slots, uint32_t *csize)
+{
+    __shared__ __attribute__((aligned(16))) RansEncLds S;
+    if (blockIdx.x >= info->n_rgroups) return;
+    const uint4 gd = rmap[blockIdx.x];
+    const uint32_t chunk = gd.x, M = gd.z & 0xFFFFFFu;
+    rans_encode_group(S, arena + gd.y, M, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk]);
 }
 
 // ---- headers stream: model (sequences + literals per chunk), Sequences_Sections, then the entropy stage over the literals
@@ -1338,11 +1354,12 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
     PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, npos));
     const uint32_t group_cap = e.chunk_cap / FQZ_GROUP + FQZ_NS * e.block_cap + 8;
-    if ((rc = e.gmap.ensure(32ull * group_cap))) return rc; // gmap | hmap
+    if ((rc = e.gmap.ensure(48ull * group_cap))) return rc; // gmap | hmap | rmap
     if ((rc = e.xmap.ensure(16ull * group_cap + 4ull * (e.chunk_cap + 8)))) return rc;
     uint32_t *xsum = (uint32_t *)(e.xmap.as<uint4>() + group_cap);
     uint32_t *cinfo = csize + e.chunk_cap + 2, *hord = csize + 2ull * e.chunk_cap + 4;
     uint4 *hmap = e.gmap.as<uint4>() + group_cap;
+    uint4 *rmap = (flags & FQZ_BATCH_V3) ? hmap + group_cap : nullptr; // container version 3: the qualities are coded by k_rans
     // side buffers of the headers model: per headers chunk its sequences, literals, Sequences_Section (fqz_hdrlz.h).  Sized for
     // a quarter of the text being headers; a batch with more is relaunched with the exact need (fqz_enc_finish)
     uint32_t hcap = (uint32_t)(n / (4ull * FQZ_CHUNK)) + 2 * e.block_cap + 64;
@@ -1361,7 +1378,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     uint32_t *hlist = (uint32_t *)(hside + hcap);
     uint16_t *hhist = (uint16_t *)(hlist + hcap);
     PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), hmap, e.xmap.as<uint4>(), group_cap,
-                                                    cinfo, csize, hord, hlist, hcap));
+                                                    cinfo, csize, hord, hlist, hcap, rmap));
     // the content checksums need the streams only: they are hashed on a side stream beside the entropy coder (a chain of
     // memory round trips with a few waves per CU beside a kernel bound by instruction issue) and joined before k_compact
     if (!e.side) {
@@ -1398,6 +1415,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     HIP_TRY(hipEventRecord(e.ev_join3, e.side3));
     PROF(ctx, sd, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, sd, info, hmap, arena, slots, csize, hord, hcap, hlit, hside, hhist));
     HIP_TRY(hipEventRecord(e.ev_join, e.side));
+    if (rmap) PROF(ctx, st, "k_rans", hipLaunchKernelGGL(k_rans, dim3(group_cap), dim3(64), 0, st, info, rmap, arena, slots, csize));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join, 0));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join2, 0));
@@ -1530,7 +1548,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     if ((rc = e.xmap.ensure(16ull * group_cap + 4ull * (chunks + 8)))) return rc;
     uint32_t *xsum = (uint32_t *)(e.xmap.as<uint4>() + group_cap);
     hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), (uint4 *)nullptr, e.xmap.as<uint4>(), group_cap, csize + chunks + 2, csize,
-                       (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint4 *)nullptr);
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
     PROF(ctx, st, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, st, info, e.xmap.as<uint4>(), d_src, d_src, xsum));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;

@@ -35,6 +35,7 @@ struct EncInfo {
     uint32_t n_xgroups;     // all chunk groups = zstd frames, the Raw ones of the packed bases included (k_xxh)
     uint32_t n_hchunks;     // chunks of the headers streams (modelled before the entropy stage, fqz_hdrlz.h)
     uint32_t n_hgroups;     // their groups
+    uint32_t n_rgroups;     // groups of the quality streams when they are coded with rANS (container version 3, fqz_rans.h)
     unsigned long long error_key; // (record << 8 | check order << 4 | code index), min wins
     unsigned long long out_len;
     unsigned long long stream_raw[FQZ_NS];
@@ -62,6 +63,8 @@ struct DecInfo {
     unsigned long long out_len;
     unsigned long long stream_raw[FQZ_NS];
     unsigned long long stream_comp[FQZ_NS];
+    uint32_t n_rgroups;     // groups with rANS blocks (version-3 files; appended by k_dec_index)
+    uint32_t pad_;
 };
 
 #define HIP_TRY(expr)                                   \

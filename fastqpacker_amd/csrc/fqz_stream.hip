@@ -162,8 +162,10 @@ struct ShardRole {
 
 static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts, const ShardRole *role = nullptr)
 {
-    fqz_options o = {FQZ_DEFAULT_BLOCK_SIZE, 0};                       // compress.go:126-128 (nil opts)
+    fqz_options o = {FQZ_DEFAULT_BLOCK_SIZE, 0, 0};                    // compress.go:126-128 (nil opts)
     if (opts) o = *opts;
+    if (o.container_version && o.container_version != FQZ_VERSION2 && o.container_version != FQZ_VERSION3) return FQZ_E_FILE_VERSION;
+    const bool v3 = o.container_version == FQZ_VERSION3;
     if (!o.block_size) o.block_size = FQZ_DEFAULT_BLOCK_SIZE;          // compress.go:129-131
     const uint32_t rpb = FQZ_DEFAULT_BLOCK_SIZE;                       // batches are always 100 000 records (compress.go:48-52, App. B-4)
     HIP_TRY(hipSetDevice(ctx->device));
@@ -232,7 +234,7 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts, const Sha
         if ((rc = lane->d_out.ensure(cap + 64))) { P.fail(rc); break; }
         fqz_batch_result res;
         for (int attempt = 0;; attempt++) {
-            rc = fqz_enc_launch(lane, d_text, n_text, rpb, enc, final_batch ? FQZ_BATCH_FINAL : 0, lane->d_out.as<uint8_t>(), cap, lane->stream);
+            rc = fqz_enc_launch(lane, d_text, n_text, rpb, enc, (final_batch ? FQZ_BATCH_FINAL : 0u) | (v3 ? FQZ_BATCH_V3 : 0u), lane->d_out.as<uint8_t>(), cap, lane->stream);
             if (!rc) rc = fqz_enc_finish(lane, &res, nullptr, nullptr, 0);
             if (rc == FQZ_E_TOO_LARGE && attempt < 3) continue; // the context has resized itself (very short lines): same launch again
             break;
@@ -242,7 +244,7 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts, const Sha
         if (first && (final_batch || res.n_blocks)) { // block 0 is in this batch: its records decided the encoding (a batch that held less than one block decides nothing)
             enc = res.qual_encoding;
             if (enc == FQZ_ENCODING_PHRED64) flags |= FQZ_FLAG_PHRED64; // compress.go:162-164
-            fqz_file_header fh = {FQZ_VERSION2, o.block_size, flags};  // compress.go:157-161
+            fqz_file_header fh = {(uint8_t)(v3 ? FQZ_VERSION3 : FQZ_VERSION2), o.block_size, flags};  // compress.go:157-161
             fqz_write_file_header(&fh, s.header);
             s.header_first = true;
             first = false;
@@ -286,7 +288,7 @@ static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *op
         rc = fqz_read_file_header(hdr, (size_t)got, &fh);               // compress.go:567-570
         if (rc) return rc;
     }
-    if (fh.version != FQZ_VERSION1 && fh.version != FQZ_VERSION2) return FQZ_E_FILE_VERSION; // compress.go:571-573
+    if (fh.version != FQZ_VERSION1 && fh.version != FQZ_VERSION2 && fh.version != FQZ_VERSION3) return FQZ_E_FILE_VERSION; // compress.go:571-573
     const int enc = (fh.flags & FQZ_FLAG_PHRED64) ? FQZ_ENCODING_PHRED64 : FQZ_ENCODING_PHRED33; // compress.go:576-579
     Pipe P(ctx);
     for (int i = 0; i < NS; i++) P.slot[i].lane = ctx->lanes[i];
@@ -706,7 +708,7 @@ extern "C" int fqz_decompress_multi(const int *devices, int n_devices, const uin
     fqz_file_header fh;
     int rc = fqz_read_file_header(fqz, n, &fh);
     if (rc) return rc;
-    if (fh.version != FQZ_VERSION1 && fh.version != FQZ_VERSION2) return FQZ_E_FILE_VERSION;
+    if (fh.version != FQZ_VERSION1 && fh.version != FQZ_VERSION2 && fh.version != FQZ_VERSION3) return FQZ_E_FILE_VERSION;
     // block boundaries
     std::vector<size_t> starts;
     size_t pos = FQZ_FILE_HEADER_SIZE;

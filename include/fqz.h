@@ -78,6 +78,11 @@ const char *fqz_version(void);
 #define FQZ_FLAG_PHRED64 0x02          /* fqformat.FlagPhred64               container.go:16 */
 #define FQZ_VERSION1 1                 /* fqformat.Version1                  container.go:21 */
 #define FQZ_VERSION2 2                 /* fqformat.Version2 (= CurrentVersion) container.go:22-24 */
+/* Version 3 ("FQZ-R1"; not a reference format: the stock decoder rejects it by its version byte,
+ * compress.go:571-573): a version-2 file whose quality payloads carry interleaved-rANS blocks (zstd's reserved block type
+ * 3) in the place of Huffman-coded literals - order-0 entropy instead of >= 1 bit a symbol.  Written on request only
+ * (fqz_options.container_version = 3 / FQZ_BATCH_V3); read by every decode entry point. */
+#define FQZ_VERSION3 3
 #define FQZ_FILE_HEADER_SIZE 10
 #define FQZ_ENTROPY_CHUNK 16384u       /* bytes of a pre-entropy stream per zstd block */
 
@@ -143,6 +148,7 @@ typedef struct {
 } fqz_batch_result;
 
 #define FQZ_DETECT_ENCODING (-1)  /* run encoder.DetectEncoding (quality.go:22) over the first block on the GPU */
+#define FQZ_BATCH_V3 2u           /* write FQZ_VERSION3 blocks: the quality stream in rANS blocks (the caller writes version 3 into the file header) */
 #define FQZ_BATCH_FINAL 1u        /* last batch of the input: a short last block is emitted, an unterminated tail is dropped (parser.go:210-220) */
 
 /* Encodes records_per_block-record blocks from FASTQ text already in HBM.
@@ -208,6 +214,7 @@ int fqz_entropy_decode(fqz_ctx *ctx, const uint8_t *src, size_t n, uint8_t *dst,
 typedef struct {          /* compress.Options compress.go:74-77 */
     uint32_t block_size;  /* BlockSize: written to the file header only; 0 -> 100000 */
     int32_t  workers;     /* Workers: kept for API parity; the GPU pipeline sizes itself. 0 -> default */
+    uint32_t container_version; /* 0 or 2: CurrentVersion (container.go:24); 3: FQZ_VERSION3 */
 } fqz_options;
 typedef struct {          /* compress.DecompressOptions compress.go:80-82 */
     int32_t workers;

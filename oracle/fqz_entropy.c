@@ -36,6 +36,7 @@
 #define FSE_W_MAXLOG 6
 
 static inline int highbit32(uint32_t v) { return 31 - __builtin_clz(v); }
+static inline void put32le(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 
 /* ===================================================================== */
 /* Huffman code lengths                                                   */
@@ -635,6 +636,142 @@ size_t fqzo_encode_group(const uint8_t *src, size_t M, int last, uint8_t *dst) {
 /* a single chunk = a group of one */
 size_t fqzo_encode_chunk(const uint8_t *src, size_t m, int last, uint8_t *dst) { return fqzo_encode_group(src, m, last, dst); }
 
+
+/* ===================================================================== */
+/* FQZ-R1: interleaved rANS blocks (container version 3)   */
+/* ===================================================================== */
+/* A version-3 file is a version-2 file (same headers, same six payloads, same FQZ-H2 framing: index frame, one frame per
+ * group, content checksums) in which the blocks of the QUALITY payload may have Block_Type 3 - reserved in RFC 8878, so
+ * these payloads are no longer zstd and the stock decoder rejects the file by its version (compress.go:571-573):
+ *
+ *   Block_Header (3 bytes, type 3, Block_Size = what follows)
+ *   u16le m          bytes the block regenerates (1..16384)
+ *   u8    tflag      1: a frequency table follows - in the first type-3 block of a frame and only there - else 0
+ *   [ u8 nsym-1 | nsym symbols, ascending | nsym x u16le frequency (1..4095, sum 4096) | a zero byte if nsym is even ]
+ *   16-bit words     little endian, in the order the encoder emitted them
+ *   16 x u32le       the final states of the 16 coders (lane 0 first)
+ *
+ * Sixteen order-0 rANS coders (state in [2^16, 2^32), 12-bit frequencies, 16-bit renormalisation) share the block: byte i
+ * belongs to coder (i >> 4) & 15 - sixteen consecutive bytes a coder, so a decoder lane stores 16-byte units - and is its
+ * ((i >> 8) << 4 | (i & 15))-th symbol ("step").  The encoder runs the steps from the last to the first, within a step
+ * the coders from 15 down to 0, every coder starting at 2^16, and appends a word whenever a coder renormalises; the
+ * decoder starts from the final states, runs steps and coders upwards, takes its words from the end of the word area
+ * backwards, and must arrive at the start of the word area with every state back at 2^16 (which is checked).
+ * Frequencies: round(count * 4096 / M) over the group's histogram, at least 1, the rounding error goes to the most
+ * frequent symbol (the smallest one on ties). */
+#define RANS_L 65536u
+typedef struct { uint16_t freq[256], cum[256]; uint8_t ser[1 + 3 * 256 + 1]; size_t ser_len; } rans_tab;
+
+static int rans_normalise(const uint32_t count[256], uint32_t M, rans_tab *t)
+{
+    int best = -1, n_active = 0;
+    uint32_t sum = 0;
+    for (int sy = 0; sy < 256; sy++) {
+        t->freq[sy] = 0;
+        if (!count[sy]) continue;
+        uint32_t f = (count[sy] * 8192u + M) / (2u * M);
+        if (!f) f = 1;
+        t->freq[sy] = (uint16_t)f;
+        sum += f;
+        n_active++;
+        if (best < 0 || count[sy] > count[best]) best = sy;
+    }
+    if (n_active < 2) return 0;
+    const int fixed = (int)t->freq[best] + 4096 - (int)sum;
+    if (fixed < 1) return 0; /* (cannot happen for histograms that pass the flatness test; the group is then stored raw) */
+    t->freq[best] = (uint16_t)fixed;
+    uint32_t c = 0;
+    uint8_t *o = t->ser;
+    *o++ = (uint8_t)(n_active - 1);
+    for (int sy = 0; sy < 256; sy++) if (t->freq[sy]) *o++ = (uint8_t)sy;
+    for (int sy = 0; sy < 256; sy++) {
+        t->cum[sy] = (uint16_t)c;
+        c += t->freq[sy];
+        if (t->freq[sy]) { *o++ = (uint8_t)t->freq[sy]; *o++ = (uint8_t)(t->freq[sy] >> 8); }
+    }
+    if (!(n_active & 1)) *o++ = 0;
+    t->ser_len = (size_t)(o - t->ser);
+    return n_active;
+}
+
+/* content of a type-3 block (without the 3-byte block header); dst holds 6 + 770 + 2 m + 64 bytes */
+static size_t rans_block_content(const uint8_t *c, uint32_t m, const rans_tab *t, int with_table, uint8_t *dst)
+{
+    uint8_t *op = dst;
+    *op++ = (uint8_t)m; *op++ = (uint8_t)(m >> 8); *op++ = with_table ? 1 : 0;
+    if (with_table) { memcpy(op, t->ser, t->ser_len); op += t->ser_len; }
+    uint32_t x[16];
+    for (int j = 0; j < 16; j++) x[j] = RANS_L;
+    const uint32_t steps = 16 * ((m + 255) / 256);
+    for (uint32_t st = steps; st-- > 0;)
+        for (int j = 15; j >= 0; j--) {
+            const uint32_t i = ((st >> 4) << 8) | ((uint32_t)j << 4) | (st & 15);
+            if (i >= m) continue;
+            const uint32_t f = t->freq[c[i]];
+            if (x[j] >= (f << 20)) { *op++ = (uint8_t)x[j]; *op++ = (uint8_t)(x[j] >> 8); x[j] >>= 16; }
+            x[j] = ((x[j] / f) << 12) + (x[j] % f) + t->cum[c[i]];
+        }
+    for (int j = 0; j < 16; j++) { put32le(op, x[j]); op += 4; }
+    return (size_t)(op - dst);
+}
+
+/* a group of the quality stream of a version-3 file: same decisions as encode_group_chunks (RLE block for a chunk of one
+ * byte, Raw blocks for short or near-flat groups, Raw block for a chunk that coding does not shrink), rANS in the place of
+ * the Huffman-coded literals */
+static size_t encode_group_rans(const uint8_t *src, size_t M, uint8_t *dst)
+{
+    /* the histogram covers the chunks that are coded: a chunk of one repeated byte becomes an RLE block and stays out of it */
+    uint32_t count[256] = {0}, Mc = 0;
+    int same_k[FQZO_GROUP] = {0};
+    for (size_t off = 0, k = 0; off < M; off += FQZO_CHUNK, k++) {
+        const uint32_t mk = (uint32_t)(M - off < FQZO_CHUNK ? M - off : FQZO_CHUNK);
+        int same = 1;
+        for (uint32_t i = 1; same && i < mk; i++) if (src[off + i] != src[off]) same = 0;
+        same_k[k] = same;
+        if (same) continue;
+        for (uint32_t i = 0; i < mk; i++) count[src[off + i]]++;
+        Mc += mk;
+    }
+    int coded = 1, n_active = 0;
+    for (int sy = 0; sy < 256; sy++) n_active += count[sy] != 0;
+    if (n_active <= 1 || Mc < 64) coded = 0;
+    else {
+        uint64_t sq = 0;
+        for (int sy = 0; sy < 256; sy++) sq += (uint64_t)count[sy] * count[sy];
+        if (sq * 230 <= (uint64_t)Mc * Mc) coded = 0;
+    }
+    rans_tab tab;
+    if (coded && !rans_normalise(count, Mc, &tab)) coded = 0;
+    /* the first chunk that is not RLE carries the table; if coding does not shrink it, the group is not coded at all */
+    uint8_t *tmp = (uint8_t *)malloc(6 + sizeof tab.ser + 2 * (size_t)FQZO_CHUNK + 64);
+    int carrier = -1;
+    for (size_t off = 0, k = 0; off < M && carrier < 0; off += FQZO_CHUNK, k++) if (!same_k[k]) carrier = (int)k;
+    if (coded) {
+        const size_t off = (size_t)carrier * FQZO_CHUNK;
+        const uint32_t mk = (uint32_t)(M - off < FQZO_CHUNK ? M - off : FQZO_CHUNK);
+        if (rans_block_content(src + off, mk, &tab, 1, tmp) >= mk) coded = 0;
+    }
+    uint8_t *out = dst;
+    for (size_t off = 0; off < M; off += FQZO_CHUNK) {
+        const uint32_t mk = (uint32_t)(M - off < FQZO_CHUNK ? M - off : FQZO_CHUNK);
+        const uint8_t *c = src + off;
+        const int lastblk = off + mk == M, k = (int)(off / FQZO_CHUNK);
+        if (same_k[k]) { put_block_header(out, lastblk, 1, mk); out[3] = c[0]; out += 4; continue; }
+        if (coded) {
+            const size_t content = rans_block_content(c, mk, &tab, k == carrier, tmp);
+            if (content < mk) { /* (always, for the carrier) */
+                put_block_header(out, lastblk, 3, (uint32_t)content);
+                memcpy(out + 3, tmp, content);
+                out += 3 + content;
+                continue;
+            }
+        }
+        out += raw_block(c, mk, lastblk, out);
+    }
+    free(tmp);
+    return (size_t)(out - dst);
+}
+
 /* ===================================================================== */
 /* frame                                                                  */
 /* ===================================================================== */
@@ -684,7 +821,6 @@ uint64_t fqzo_xxh64(const uint8_t *p, size_t len, uint64_t seed)
  * Frames are independent, so encoder and decoder work on every group in parallel and the content checksum (an
  * inherently serial hash) runs over 64 KiB at a time, one hash per four lanes. */
 #define FQZO_IDX_HDR 24 /* magic 4 + size 4 + 'FQZI' 4 + version, stream, flags 4 + raw length 4 + block count 4 */
-static inline void put32le(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 
 size_t fqzo_entropy_bound(size_t n)
 {
@@ -693,7 +829,9 @@ size_t fqzo_entropy_bound(size_t n)
     return FQZO_IDX_HDR + 3 * chunks + (4 + 4 * (n / 128 + 1)) /* record samples: a record is >= 2 bytes */ + groups * (7 + 4) + n + 3 * chunks;
 }
 
-size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint8_t *dst)
+size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint8_t *dst) { return fqzo_entropy_encode_stream_v(src, n, stream, 2, dst); }
+
+size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, int version, uint8_t *dst)
 {
     if (!n) return 0;
     const size_t chunks = (n + FQZO_CHUNK - 1) / FQZO_CHUNK;
@@ -748,7 +886,8 @@ size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint
                 ch[nch].n_lit = nl;
             }
             body = encode_group_chunks(ch, nch, 0, op);
-        } else body = encode_group_ex(src + off, M, 1, stream == 0, op);
+        } else if (version == 3 && stream == 1) body = encode_group_rans(src + off, M, op); /* FQZ-R1 */
+        else body = encode_group_ex(src + off, M, 1, stream == 0, op);
         /* the index lists the size of every zstd block of the group */
         for (size_t q = 0; q < body;) {
             const uint32_t bh = op[q] | ((uint32_t)op[q + 1] << 8) | ((uint32_t)op[q + 2] << 16);
@@ -1166,7 +1305,7 @@ long fqzo_entropy_content_size(const uint8_t *src, size_t n)
             const uint32_t bh = src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16);
             const uint32_t type = (bh >> 1) & 3, bs = bh >> 3;
             const size_t adv = 3 + (type == 1 ? 1u : bs);
-            if (type == 3 || adv > n - ip) return FQZO_E_ENTROPY;
+            if (adv > n - ip) return FQZO_E_ENTROPY; /* (type 3: a FQZ-R1 block, sized like a Compressed block) */
             ip += adv;
             if (bh & 1) break;
         }
@@ -1175,6 +1314,61 @@ long fqzo_entropy_content_size(const uint8_t *src, size_t n)
         if (total > 0x7FFFFFFFull) return FQZO_E_ENTROPY;
     }
     return (long)total;
+}
+
+/* FQZ-R1 block (see the encoder): returns the bytes regenerated or a negative error */
+typedef struct { int valid; uint16_t freq[256], cum[256]; uint8_t slot[4096]; } rans_dtab;
+static long rans_decode_block(const uint8_t *src, size_t bs, uint8_t *dst, size_t cap, rans_dtab *t)
+{
+    if (bs < 3 + 64) return FQZO_E_ENTROPY;
+    const uint32_t m = src[0] | ((uint32_t)src[1] << 8);
+    if (m < 1 || m > FQZO_CHUNK || (src[2] & ~1u)) return FQZO_E_ENTROPY;
+    if (m > cap) return FQZO_E_DST_SMALL;
+    size_t p = 3;
+    if (src[2] & 1) {
+        if (t->valid) return FQZO_E_ENTROPY; /* one table a frame */
+        const uint32_t nsym = (uint32_t)src[p] + 1;
+        const size_t tl = 1 + 3 * (size_t)nsym + ((nsym & 1) ? 0 : 1);
+        if (nsym < 2 || p + tl + 64 > bs) return FQZO_E_ENTROPY;
+        const uint8_t *sy = src + p + 1, *fr = sy + nsym;
+        uint32_t c = 0;
+        memset(t->freq, 0, sizeof t->freq);
+        for (uint32_t k = 0; k < nsym; k++) {
+            const uint32_t f = fr[2 * k] | ((uint32_t)fr[2 * k + 1] << 8);
+            if ((k && sy[k] <= sy[k - 1]) || f < 1 || f > 4095 || c + f > 4096) return FQZO_E_ENTROPY;
+            t->freq[sy[k]] = (uint16_t)f; t->cum[sy[k]] = (uint16_t)c;
+            memset(t->slot + c, sy[k], f);
+            c += f;
+        }
+        if (c != 4096 || (!(nsym & 1) && src[p + tl - 1] != 0)) return FQZO_E_ENTROPY;
+        t->valid = 1;
+        p += tl;
+    } else if (!t->valid) return FQZO_E_ENTROPY;
+    const size_t states = bs - 64;
+    if ((states - p) & 1) return FQZO_E_ENTROPY;
+    uint32_t x[16];
+    for (int j = 0; j < 16; j++) {
+        x[j] = src[states + 4 * j] | ((uint32_t)src[states + 4 * j + 1] << 8) | ((uint32_t)src[states + 4 * j + 2] << 16) | ((uint32_t)src[states + 4 * j + 3] << 24);
+        if (x[j] < RANS_L) return FQZO_E_ENTROPY;
+    }
+    size_t wp = states;
+    const uint32_t steps = 16 * ((m + 255) / 256);
+    for (uint32_t st = 0; st < steps; st++)
+        for (int j = 0; j < 16; j++) {
+            const uint32_t i = ((st >> 4) << 8) | ((uint32_t)j << 4) | (st & 15);
+            if (i >= m) continue;
+            const uint32_t sl = x[j] & 4095u, sy = t->slot[sl];
+            dst[i] = (uint8_t)sy;
+            x[j] = t->freq[sy] * (x[j] >> 12) + sl - t->cum[sy];
+            if (x[j] < RANS_L) {
+                if (wp < p + 2) return FQZO_E_ENTROPY;
+                wp -= 2;
+                x[j] = (x[j] << 16) | src[wp] | ((uint32_t)src[wp + 1] << 8);
+            }
+        }
+    if (wp != p) return FQZO_E_ENTROPY;
+    for (int j = 0; j < 16; j++) if (x[j] != RANS_L) return FQZO_E_ENTROPY;
+    return (long)m;
 }
 
 long fqzo_entropy_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
@@ -1194,6 +1388,7 @@ long fqzo_entropy_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
         size_t frame_start = out;
         huf_state *hs = (huf_state *)calloc(1, sizeof(huf_state));
         if (!hs) return FQZO_E_ENTROPY;
+        rans_dtab *rt = NULL;
         long err = 0;
         for (;;) {
             if (ip + 3 > n) { err = FQZO_E_ENTROPY; break; }
@@ -1216,10 +1411,17 @@ long fqzo_entropy_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
                 long r = decode_compressed_block(src + ip, bs, dst + out, cap - out, hs);
                 if (r < 0) { err = r; break; }
                 ip += bs; out += (size_t)r;
-            } else { err = FQZO_E_ENTROPY; break; }
+            } else { /* type 3: FQZ-R1 (version-3 files) */
+                if (ip + bs > n) { err = FQZO_E_ENTROPY; break; }
+                if (!rt && !(rt = (rans_dtab *)calloc(1, sizeof(rans_dtab)))) { err = FQZO_E_ENTROPY; break; }
+                long r = rans_decode_block(src + ip, bs, dst + out, cap - out, rt);
+                if (r < 0) { err = r; break; }
+                ip += bs; out += (size_t)r;
+            }
             if (last) break;
         }
         free(hs);
+        free(rt);
         if (err) return err;
         if (ck) { /* Content_Checksum: low 32 bits of XXH64 over the frame's content; a mismatch is an error */
             if (ip + 4 > n) return FQZO_E_ENTROPY;

@@ -145,7 +145,7 @@ int fqzo_write_block_header(const fqzo_block_header *b, uint8_t version, uint8_t
         put32(out + 24, b->original_seq_size); put32(out + 28, b->original_qual_size);
         return 32;
     }
-    if (version == 2) { /* container.go:97-109 */
+    if (version == 2 || version == 3) { /* container.go:97-109 (version 3 keeps the 36-byte header) */
         put32(out + 0, b->num_records); put32(out + 4, b->seq_size); put32(out + 8, b->qual_size);
         put32(out + 12, b->header_size); put32(out + 16, b->plus_size); put32(out + 20, b->npos_size);
         put32(out + 24, b->lengths_size); put32(out + 28, b->original_seq_size); put32(out + 32, b->original_qual_size);
@@ -164,7 +164,7 @@ int fqzo_read_block_header(const uint8_t *in, size_t n, uint8_t version, fqzo_bl
         b->original_seq_size = get32(in + 24); b->original_qual_size = get32(in + 28);
         return 32;
     }
-    if (version == 2) { /* container.go:133-148 */
+    if (version == 2 || version == 3) { /* container.go:133-148 */
         if (n < 36) return FQZO_E_SHORT;
         b->num_records = get32(in); b->seq_size = get32(in + 4); b->qual_size = get32(in + 8);
         b->header_size = get32(in + 12); b->plus_size = get32(in + 16); b->npos_size = get32(in + 20);
@@ -511,7 +511,7 @@ static void encode_block_job(enc_job *j)
             comp[k] = s.len[k] ? zs.compress(out + w, cap - w, s.data[k], s.len[k], 1) : 0;
             if (zs.is_error(comp[k])) { free(out); fqzo_streams_free(&s); j->err = FQZO_E_ENTROPY; return; }
         } else {
-            comp[k] = fqzo_entropy_encode_stream(s.data[k], s.len[k], k, out + w);
+            comp[k] = fqzo_entropy_encode_stream_v(s.data[k], s.len[k], k, j->entropy == 2 ? 3 : 2, out + w);
         }
         w += comp[k];
     }
@@ -593,7 +593,7 @@ long fqzo_compress(const uint8_t *fastq, size_t n, uint8_t *out, size_t cap, con
 
     /* compress.go:157-168 */
     if (cap < 10) { free(recs); return FQZO_E_DST_SMALL; }
-    fqzo_file_header fh = { 2, o.block_size, (uint8_t)(enc == FQZO_PHRED64 ? FQZO_FLAG_PHRED64 : 0) };
+    fqzo_file_header fh = { (uint8_t)(o.entropy == 2 ? 3 : 2), o.block_size, (uint8_t)(enc == FQZO_PHRED64 ? FQZO_FLAG_PHRED64 : 0) };
     fqzo_write_file_header(&fh, out);
     size_t w = 10;
 
@@ -733,7 +733,7 @@ long fqzo_decompress(const uint8_t *fqz, size_t n, uint8_t *out, size_t cap, int
     fqzo_file_header fh;
     int e = fqzo_read_file_header(fqz, n, &fh); /* compress.go:567-570 */
     if (e) return e;
-    if (fh.version != 1 && fh.version != 2) return FQZO_E_FILE_VERSION; /* compress.go:571-573 */
+    if (fh.version != 1 && fh.version != 2 && fh.version != 3) return FQZO_E_FILE_VERSION; /* compress.go:571-573; 3 = FQZ-R1 (ours) */
     int enc = (fh.flags & FQZO_FLAG_PHRED64) ? FQZO_PHRED64 : FQZO_PHRED33; /* compress.go:576-579 */
 
     /* readNextDecompressJob / readCompressedStreams, compress.go:721-758 */

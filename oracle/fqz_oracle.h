@@ -155,6 +155,8 @@ size_t fqzo_entropy_bound(size_t n);
 size_t fqzo_entropy_encode(const uint8_t *src, size_t n, uint8_t *dst);
 /* the payload of stream `stream` (0 seq .. 5 lengths) of a block: the 2-bit packed bases are Raw by definition */
 size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint8_t *dst);
+/* version 3 (FQZ-R1): the quality stream (stream 1) is coded with interleaved rANS blocks; version 2 = the above */
+size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, int version, uint8_t *dst);
 /* XXH64 (zstd content checksum = its low 32 bits, seed 0) */
 uint64_t fqzo_xxh64(const uint8_t *p, size_t len, uint64_t seed);
 /* Decoder for any zstd frame made only of Raw / RLE / Compressed blocks whose
@@ -183,7 +185,8 @@ typedef struct {
     uint32_t block_size;    /* Options.BlockSize (compress.go:75); 0 -> 100000 */
     int workers;            /* Options.Workers (compress.go:76); 0 -> all cores */
     uint32_t batch_records; /* records per block; 0 -> 100000 (batchPool, compress.go:48-52) */
-    int entropy;            /* 0 = FQZ-H2 frames (Huffman literals); 1 = system libzstd level 1 via dlopen (CPU-baseline leg) */
+    int entropy;            /* 0 = FQZ-H2 frames (Huffman literals); 1 = system libzstd level 1 via dlopen (CPU-baseline leg);
+                             * 2 = container version 3 (FQZ-R1: FQZ-H2 with rANS-coded qualities) */
     int force_encoding;     /* 0 = DetectEncoding on the first batch (compress.go:146-154); 1 = Phred+33, 2 = Phred+64: a shard of a
                              * file whose first batch another process saw (multi-GPU sharding: rank 0 detects and broadcasts) */
 } fqzo_options;

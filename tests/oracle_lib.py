@@ -94,6 +94,8 @@ def lib():
         L.fqzo_entropy_encode.argtypes = [C.c_char_p, C.c_size_t, u8p]
         L.fqzo_entropy_encode_stream.restype = C.c_size_t
         L.fqzo_entropy_encode_stream.argtypes = [C.c_char_p, C.c_size_t, C.c_int, u8p]
+        L.fqzo_entropy_encode_stream_v.restype = C.c_size_t
+        L.fqzo_entropy_encode_stream_v.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, u8p]
         L.fqzo_xxh64.restype = C.c_uint64
         L.fqzo_xxh64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
         L.fqzo_entropy_decode.restype = C.c_long
@@ -212,11 +214,12 @@ def join_block(streams, num_records, enc, cap=None):
     return bytes(out[:r])
 
 
-def entropy_encode(src: bytes, stream: int = 1) -> bytes:
-    """FQZ-H2 payload of one pre-entropy stream (stream 0 = 2-bit packed bases: Raw blocks by definition)."""
+def entropy_encode(src: bytes, stream: int = 1, version: int = 2) -> bytes:
+    """FQZ-H2 payload of one pre-entropy stream (stream 0 = 2-bit packed bases: Raw blocks by definition); version 3: FQZ-R1
+    (the quality stream, stream 1, in interleaved rANS blocks)."""
     cap = lib().fqzo_entropy_bound(len(src)) + 16
     out = bytearray(cap)
-    n = lib().fqzo_entropy_encode_stream(src, len(src), stream, _u8(out))
+    n = lib().fqzo_entropy_encode_stream_v(src, len(src), stream, version, _u8(out))
     return bytes(out[:n])
 
 

@@ -47,7 +47,7 @@ def test_container_framing_is_byte_exact_on_host():
     got, n = fqformat.ReadBlockHeader(b1, 1)
     assert n == 32 and got[4] == 0 and got[5] == 10
     with pytest.raises(fq.FqzError, match="unsupported block header version"):
-        fqformat.WriteBlockHeader(f, 3)
+        fqformat.WriteBlockHeader(f, 4)
     # same bytes as the oracle's framing
     import oracle_lib as O
     bh = O.BlockHeader(*f)

@@ -85,7 +85,7 @@ def test_v1_container_and_errors(fq):
     bh = b"".join(x.to_bytes(4, "little") for x in [1] + [len(c) for c in comp] + [8, 8])
     assert fq.compress.Decompress(fh + bh + b"".join(comp)) == text
     with pytest.raises(fq.FqzError, match="unsupported file version"):
-        fq.compress.Decompress(bytes.fromhex("46515a00") + bytes([3]) + bytes(5))
+        fq.compress.Decompress(bytes.fromhex("46515a00") + bytes([4]) + bytes(5))
     with pytest.raises(fq.FqzError, match="invalid magic"):
         fq.compress.Decompress(b"XYZ\x00" + bytes(6))
     z = fq.compress.Compress(text)

@@ -183,7 +183,7 @@ def test_v1_container_decodes():
     assert O.decompress(fh + bh + b"".join(comp)) == text
     # unsupported version
     with pytest.raises(O.OracleError, match="unsupported file version"):
-        O.decompress(bytes.fromhex("46515a00") + bytes([3]) + bytes(5))
+        O.decompress(bytes.fromhex("46515a00") + bytes([4]) + bytes(5))
     # truncated block header / payload
     z = O.compress(text)
     with pytest.raises(O.OracleError):
