@@ -33,6 +33,8 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--decode-steps", type=int, default=3)
     ap.add_argument("--quality-profile", type=int, default=0)
+    ap.add_argument("--container", type=int, default=2, help="container version the timed encode writes: 2 = the reference's (default), "
+                    "3 = FQZ-R1 (rANS-coded qualities, SURVEY 8 f-4; not readable by the stock decoder)")
     ap.add_argument("--inflight", type=int, default=3, help="batches in flight for the supplementary pipelined figure (0 = skip)")
     return ap.parse_args()
 
@@ -137,6 +139,9 @@ def main():
         workload = "synthetic 150 bp Phred+33 FASTQ, %.2f GB per GPU (BASELINE.json configs[1] in its '1 GB' reading), one device batch" \
                    % (batches[0].size / 1e9)
     workload += ", device-resident, 100k-record blocks, quality profile %d" % a.quality_profile
+    if a.container == 3:
+        workload += ", container version 3 (FQZ-R1: rANS-coded qualities)"
+    enc_flags = fq.BATCH_FINAL | (fq.BATCH_V3 if a.container == 3 else 0)
     d_texts = [torch.from_numpy(b).to(dev) for b in batches]
     d_outs = [torch.empty(int(lib().fqz_encode_bound(b.size)) // 2 + (1 << 20), dtype=torch.uint8, device=dev) for b in batches]
     in_bytes = int(sum(b.size for b in batches))
@@ -152,7 +157,7 @@ def main():
     def encode_step():
         for i, b in enumerate(batches):
             fq._lib.check(lib().fqz_encode_batch_dev(ctx.handle, d_texts[i].data_ptr(), b.size, RPB, fq.ENCODING_PHRED33,
-                                                     fq.BATCH_FINAL, d_outs[i].data_ptr(), d_outs[i].numel(), C.byref(ress[i]), offs[i], lens[i],
+                                                     enc_flags, d_outs[i].data_ptr(), d_outs[i].numel(), C.byref(ress[i]), offs[i], lens[i],
                                                      max_blocks, sptr))
         if world > 1:
             # container index: all-gather of per-block compressed sizes -> exclusive prefix = file offsets (RCCL over xGMI);
@@ -228,7 +233,7 @@ def main():
 
     def decode_step():
         for i in range(len(batches)):
-            fq._lib.check(lib().fqz_decode_batch_dev(ctx.handle, fqz_devs[i].data_ptr(), fqz_devs[i].numel(), 2, fq.ENCODING_PHRED33,
+            fq._lib.check(lib().fqz_decode_batch_dev(ctx.handle, fqz_devs[i].data_ptr(), fqz_devs[i].numel(), a.container, fq.ENCODING_PHRED33,
                                                      d_backs[i].data_ptr(), d_backs[i].numel(), C.byref(dress[i]), sptr))
     try:
         decode_step()
@@ -319,7 +324,7 @@ def main():
 
             def p_launch(i):
                 fq._lib.check(lib().fqz_encode_batch_launch(pctx[i].handle, d_text.data_ptr(), text_np.size, RPB, fq.ENCODING_PHRED33,
-                                                            fq.BATCH_FINAL, pouts[i].data_ptr(), pouts[i].numel(), C.c_void_p(pstreams[i].cuda_stream)))
+                                                            enc_flags, pouts[i].data_ptr(), pouts[i].numel(), C.c_void_p(pstreams[i].cuda_stream)))
                 busy[i] = True
 
             psteps = max(2 * nc, a.steps)
@@ -339,6 +344,42 @@ def main():
             del pctx, pouts
         except Exception as e:
             out["pipelined"] = {"error": repr(e)}
+    # ---- supplementary: the same batch as a version-3 container (FQZ-R1, SURVEY 8 f-4: the qualities in interleaved rANS
+    # blocks).  Not the headline: the stock decoder does not read it.
+    if a.container == 2 and world == 1 and len(batches) == 1:
+        try:
+            r3, d3 = BatchResult(), BatchResult()
+            d_out3 = torch.empty_like(d_outs[0])
+
+            def enc3():
+                fq._lib.check(lib().fqz_encode_batch_dev(ctx.handle, d_texts[0].data_ptr(), batches[0].size, RPB, fq.ENCODING_PHRED33,
+                                                         fq.BATCH_FINAL | fq.BATCH_V3, d_out3.data_ptr(), d_out3.numel(), C.byref(r3), None, None, 0, sptr))
+
+            def dec3():
+                fq._lib.check(lib().fqz_decode_batch_dev(ctx.handle, d_out3.data_ptr(), int(r3.out_len), 3, fq.ENCODING_PHRED33,
+                                                         d_backs[0].data_ptr(), d_backs[0].numel(), C.byref(d3), sptr))
+            enc3()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                enc3()
+            torch.cuda.synchronize()
+            e3 = (time.perf_counter() - t0) / 5
+            d_backs[0].zero_()
+            dec3()
+            ok3 = bool(d3.out_len == batches[0].size and torch.equal(d_backs[0][: batches[0].size], d_texts[0]))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dec3()
+            torch.cuda.synchronize()
+            dd3 = (time.perf_counter() - t0) / 3
+            out["container_v3"] = {"encode_MBps": round(in_bytes / e3 / 1e6, 1), "decode_MBps": round(in_bytes / dd3 / 1e6, 1),
+                                   "ratio": round(in_bytes / int(r3.out_len), 3), "roundtrip_bit_exact": ok3,
+                                   "quality_stream_ratio": round(int(r3.stream_raw[1]) / max(1, int(r3.stream_comp[1])), 3)}
+            del d_out3
+        except Exception as e:
+            out["container_v3"] = {"error": repr(e)}
     if not a.no_cpu and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(batches[0])

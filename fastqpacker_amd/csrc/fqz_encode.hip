@@ -896,13 +896,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 }
 
 // Container version 3 (FQZ-R1): the groups of the quality streams, a wave each (fqz_rans.h)
-__global__ __launch_bounds__(64) void k_rans(const EncInfo *info, const uint4 *rmap, const uint8_t *arena, uint8_t *slots, uint32_t *csize)
+__global__ __launch_bounds__(64) void k_rans(const EncInfo *info, const uint4 *rmap, const uint8_t *arena, uint8_t *slots, uint32_t *csize, int dbg)
 {
     __shared__ __attribute__((aligned(16))) RansEncLds S;
     if (blockIdx.x >= info->n_rgroups) return;
     const uint4 gd = rmap[blockIdx.x];
     const uint32_t chunk = gd.x, M = gd.z & 0xFFFFFFu;
-    rans_encode_group(S, arena + gd.y, M, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk]);
+    rans_encode_group(S, arena + gd.y, M, slots + (size_t)chunk * FQZ_SLOT, &csize[chunk], dbg);
 }
 
 // ---- headers stream: model (sequences + literals per chunk), Sequences_Sections, then the entropy stage over the literals
@@ -1415,7 +1415,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     HIP_TRY(hipEventRecord(e.ev_join3, e.side3));
     PROF(ctx, sd, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, sd, info, hmap, arena, slots, csize, hord, hcap, hlit, hside, hhist));
     HIP_TRY(hipEventRecord(e.ev_join, e.side));
-    if (rmap) PROF(ctx, st, "k_rans", hipLaunchKernelGGL(k_rans, dim3(group_cap), dim3(64), 0, st, info, rmap, arena, slots, csize));
+    if (rmap) PROF(ctx, st, "k_rans", hipLaunchKernelGGL(k_rans, dim3(group_cap), dim3(64), 0, st, info, rmap, arena, slots, csize, getenv("FQZ_DBG_RANS") ? atoi(getenv("FQZ_DBG_RANS")) : 0));
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join, 0));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join2, 0));

@@ -26,15 +26,16 @@ __device__ __forceinline__ void rans_lds_order()
 // ---------------------------------------------------------------------------
 struct RansEncLds {
     uint32_t hist[256];
-    uint2 tab[256];      // x: floor(2^32 / f) (2^32 - 1 for f = 1), y: f | cum << 16
+    uint4 tab[256];      // x: floor(2^32 / f) (2^32 - 1 for f = 1), y: f, z: cum, w: 4096 - f
     uint8_t ser[1 + 3 * 256 + 3]; // the table as it travels: nsym - 1 | symbols | frequencies | pad to an even size
+    __attribute__((aligned(16))) uint8_t stage[4][1024]; // a chunk's words on their way out: a ring over the word area, flushed 256 bytes at a time
 };
 
 // Writes the blocks of the group's chunks into their slots (slot0 + k * FQZ_SLOT) and their sizes into csize0[k], like
 // entropy_encode_group.  One wave.  Decisions (oracle encode_group_rans): a chunk of one repeated byte is an RLE block and
 // stays out of the histogram; short or near-flat groups are Raw; the first chunk that is not RLE carries the table, and if
 // coding does not shrink it the whole group is Raw; any other chunk that coding does not shrink is a Raw block on its own.
-__device__ void rans_encode_group(RansEncLds &S, const uint8_t *src, const uint32_t M, uint8_t *slot0, uint32_t *csize0)
+__device__ void rans_encode_group(RansEncLds &S, const uint8_t *src, const uint32_t M, uint8_t *slot0, uint32_t *csize0, const int dbg = 0)
 {
     const uint32_t lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
     const uint32_t nchunk = (M + FQZ_CHUNK - 1) / FQZ_CHUNK;
@@ -50,21 +51,31 @@ __device__ void rans_encode_group(RansEncLds &S, const uint8_t *src, const uint3
         const uint8_t *csrc = src + (size_t)k * FQZ_CHUNK;
         const uint32_t b0 = (uint32_t)csrc[0] * 0x01010101u;
         uint32_t n0 = 0, differs = 0;
-        for (uint32_t off = lane * 16; off < mk; off += 64 * 16) {
-            const uint4 v = *(const uint4 *)(csrc + off); // (16-byte aligned; the arena is padded behind the last stream)
-            const uint32_t have = mk - off < 16u ? mk - off : 16u;
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        // (four loads in flight a lane: a wave walks its 64 KiB alone, and a load at a time is a memory round trip at a time)
+        for (uint32_t off0 = lane * 16; off0 < mk; off0 += 4 * 64 * 16) {
+            uint4 vv[4];
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const uint32_t valid = have >= 4u * d + 4 ? 0x80808080u : (have > 4u * d ? (0x80808080u >> (8 * (4 * d + 4 - have))) : 0u);
-                const uint32_t eq = zero_bytes(w[d]) & valid;
-                differs |= ~zero_bytes(w[d] ^ b0) & valid;
-                n0 += __popc(eq);
-                uint32_t other = valid & ~eq; // 0x80 per byte that needs an atomic
-                while (other) {
-                    const int bit = __ffs(other) - 1; // 7, 15, 23 or 31
-                    other &= other - 1;
-                    atomicAdd(&S.hist[(w[d] >> (bit - 7)) & 0xFF], 1u);
+            for (int r = 0; r < 4; r++) {
+                const uint32_t off = off0 + (uint32_t)r * 64u * 16u;
+                vv[r] = off < mk ? *(const uint4 *)(csrc + off) : make_uint4(0u, 0u, 0u, 0u); // (16-byte aligned; the arena is padded behind the last stream)
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t off = off0 + (uint32_t)r * 64u * 16u;
+                const uint32_t have = off < mk ? (mk - off < 16u ? mk - off : 16u) : 0u;
+                const uint32_t w[4] = {vv[r].x, vv[r].y, vv[r].z, vv[r].w};
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t valid = have >= 4u * d + 4 ? 0x80808080u : (have > 4u * d ? (0x80808080u >> (8 * (4 * d + 4 - have))) : 0u);
+                    const uint32_t eq = zero_bytes(w[d]) & valid;
+                    differs |= ~zero_bytes(w[d] ^ b0) & valid;
+                    n0 += __popc(eq);
+                    uint32_t other = valid & ~eq; // 0x80 per byte that needs an atomic
+                    while (other) {
+                        const int bit = __ffs(other) - 1; // 7, 15, 23 or 31
+                        other &= other - 1;
+                        atomicAdd(&S.hist[(w[d] >> (bit - 7)) & 0xFF], 1u);
+                    }
                 }
             }
         }
@@ -113,6 +124,7 @@ __device__ void rans_encode_group(RansEncLds &S, const uint8_t *src, const uint3
             }
         if (__ballot(bad) != 0ull) coded = false;
     }
+    if (dbg == 1) coded = false; // (timing experiments: histogram only)
     uint32_t tlen = 0;
     if (coded) {
         uint32_t cum_carry = 0, n_carry = 0;
@@ -125,10 +137,10 @@ __device__ void rans_encode_group(RansEncLds &S, const uint8_t *src, const uint3
             const unsigned long long bm = __ballot(f[p] != 0);
             const uint32_t rank = n_carry + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
             n_carry += (uint32_t)__popcll(bm);
-            uint2 e = make_uint2(0u, 0u);
+            uint4 e = make_uint4(0u, 0u, 0u, 0u);
             if (f[p]) {
                 e.x = f[p] == 1 ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / f[p]);
-                e.y = f[p] | (cum << 16);
+                e.y = f[p]; e.z = cum; e.w = 4096u - f[p];
                 S.ser[1 + rank] = (uint8_t)(lane + 64 * p);
                 S.ser[1 + n_active + 2 * rank] = (uint8_t)f[p];
                 S.ser[2 + n_active + 2 * rank] = (uint8_t)(f[p] >> 8);
@@ -148,8 +160,9 @@ __device__ void rans_encode_group(RansEncLds &S, const uint8_t *src, const uint3
     uint8_t *slot = slot0 + (size_t)q * FQZ_SLOT;
     const uint32_t tl = (mine && q == carrier) ? tlen : 0u;
     const uint32_t woff = 6u + tl; // block header 3, m 2, tflag 1, table
-    uint32_t x = RANS_L, wc = 0;
-    if (coded) { // (wave-uniform)
+    uint32_t x = RANS_L, wc = 0, flushed = 0;
+    uint8_t *stg = S.stage[q];
+    if (coded && dbg != 2) { // (wave-uniform; dbg 2: tables, no coding)
         const uint32_t U = (M < FQZ_CHUNK ? M + 255u : FQZ_CHUNK + 255u) / 256u; // chunk 0 is the longest: every quad runs its rounds, idle beyond its own
         auto fetch = [&](int u) -> uint4 {
             const uint32_t off = (uint32_t)u * 256u + j * 16u;
@@ -162,25 +175,50 @@ __device__ void rans_encode_group(RansEncLds &S, const uint8_t *src, const uint3
             const uint32_t off = (uint32_t)u * 256u + j * 16u;
             const uint32_t have = (mine && off < mk) ? (mk - off < 16u ? mk - off : 16u) : 0u;
             const uint32_t w[4] = {v0.x, v0.y, v0.z, v0.w};
+            // the common case - four chunks, each lane a whole unit - runs without the per-lane conditions.  The words go to a ring
+            // in LDS and leave 256 bytes at a time: a 2-byte store to global memory at every step made the kernel wait for the
+            // vector-memory pipeline (6.7 M store instructions a batch: 0.8 ms)
+            const bool fast = __ballot(have == 16u) == ~0ull;
+            if (fast) {
 #pragma unroll
-            for (int b = 15; b >= 0; b--) {
-                const uint32_t s = (w[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-                const uint2 e = S.tab[s];
-                const uint32_t fr = e.y & 0xFFFFu, cum = e.y >> 16;
-                const bool act = (uint32_t)b < have;
-                const bool need = act && x >= (fr << 20);
-                const unsigned long long mask = __ballot(need);
-                const uint32_t seg = (uint32_t)(mask >> (16 * q)) & 0xFFFFu;
-                if (need) {
-                    const uint32_t o = woff + 2u * (wc + (uint32_t)__popc(seg >> (j + 1)));
-                    if (o + 2u <= FQZ_CHUNK) *(uint16_t *)(slot + o) = (uint16_t)x; // (a block that would run past this is not kept)
-                    x >>= 16;
+                for (int b = 15; b >= 0; b--) {
+                    const uint4 e = S.tab[(w[b >> 2] >> (8 * (b & 3))) & 0xFFu];
+                    const bool need = x >= (e.y << 20);
+                    const uint32_t seg = (uint32_t)(__ballot(need) >> (16 * q)) & 0xFFFFu;
+                    if (need) *(uint16_t *)(stg + ((2u * (wc + (uint32_t)__popc(seg >> (j + 1)))) & 1023u)) = (uint16_t)x;
+                    x = need ? x >> 16 : x;
+                    wc += (uint32_t)__popc(seg);
+                    uint32_t q0 = __umulhi(x, e.x);
+                    q0 += (x - __umul24(q0, e.y)) >= e.y ? 1u : 0u; // the reciprocal rounds down: the quotient is short by at most one
+                    x = __umul24(q0, e.w) + (x + e.z);              // (q << 12) + (x - q f) + cum
                 }
-                wc += (uint32_t)__popc(seg);
-                if (act) {
-                    uint32_t q0 = __umulhi(x, e.x), r = x - q0 * fr;
-                    if (r >= fr) { q0++; r -= fr; }
-                    x = (q0 << 12) + r + cum;
+            } else {
+#pragma unroll
+                for (int b = 15; b >= 0; b--) {
+                    const uint4 e = S.tab[(w[b >> 2] >> (8 * (b & 3))) & 0xFFu];
+                    const bool act = (uint32_t)b < have;
+                    const bool need = act && x >= (e.y << 20);
+                    const uint32_t seg = (uint32_t)(__ballot(need) >> (16 * q)) & 0xFFFFu;
+                    if (need) {
+                        *(uint16_t *)(stg + ((2u * (wc + (uint32_t)__popc(seg >> (j + 1)))) & 1023u)) = (uint16_t)x;
+                        x >>= 16;
+                    }
+                    wc += (uint32_t)__popc(seg);
+                    if (act) {
+                        uint32_t q0 = __umulhi(x, e.x);
+                        q0 += (x - __umul24(q0, e.y)) >= e.y ? 1u : 0u;
+                        x = __umul24(q0, e.w) + (x + e.z);
+                    }
+                }
+            }
+            rans_lds_order();
+            for (;;) { // (a unit adds at most 512 bytes to less than 256 pending ones)
+                const bool go = mine && 2u * wc - flushed >= 256u;
+                if (__ballot(go) == 0ull) break;
+                if (go) {
+                    const uint32_t o = woff + flushed + 16u * j;
+                    if (o + 16u <= FQZ_SLOT) store_u128_unaligned(slot + o, *(const uint4 *)(stg + ((flushed + 16u * j) & 1023u))); // (a block that would run past this is not kept)
+                    flushed += 256u;
                 }
             }
             v0 = v1; v1 = v2; v2 = v3;
@@ -193,6 +231,9 @@ __device__ void rans_encode_group(RansEncLds &S, const uint8_t *src, const uint3
     const bool carrier_ok = coded && carrier < nchunk && ((fitm >> (16 * carrier)) & 1ull);
     const bool keep = fits && carrier_ok;
     if (keep) {
+        const uint32_t pend = 2u * wc - flushed, n16 = pend >> 4, rest = (pend & 15u) >> 1; // what is still in the ring (< 256 bytes)
+        if (j < n16) store_u128_unaligned(slot + woff + flushed + 16u * j, *(const uint4 *)(stg + ((flushed + 16u * j) & 1023u)));
+        if (j < rest) *(uint16_t *)(slot + woff + flushed + 16u * n16 + 2u * j) = *(const uint16_t *)(stg + ((flushed + 16u * n16 + 2u * j) & 1023u));
         store_u32_unaligned(slot + woff + 2u * wc + 4u * j, x);
         if (j == 0) {
             const uint32_t bh = ((q + 1 == nchunk) ? 1u : 0u) | (3u << 1) | (content << 3);
@@ -203,7 +244,15 @@ __device__ void rans_encode_group(RansEncLds &S, const uint8_t *src, const uint3
         for (uint32_t i = j; i < tl; i += 16) slot[6 + i] = S.ser[i];
     }
     const unsigned long long keepm = __ballot(keep);
-    __threadfence(); // (the words of a chunk that is stored raw after all are overwritten below)
+    if (dbg) return; // (timing experiments: garbage out)
+    {
+        unsigned long long all = 0;
+        for (uint32_t k = 0; k < nchunk; k++) all |= 1ull << (16 * k);
+        if ((keepm & all) == all) return; // every chunk is an rANS block: done
+    }
+    // the words of a chunk that is stored raw after all are overwritten below by other lanes of this wave: its stores have to
+    // be through first (workgroup scope: a wait, not the L2 write-back of a device-scope fence - that cost 0.2 ms a batch)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma clang loop unroll(disable)
     for (uint32_t k = 0; k < nchunk; k++) {
         if ((keepm >> (16 * k)) & 1ull) continue;
@@ -334,16 +383,18 @@ __device__ void rans_decode_group(RansDecLds &S, const uint8_t *in, const DecChu
         if (x < RANS_L) bad = true;
     }
     if (__ballot(bad) != 0ull) { *failed = true; return; }
-    // absolute input offsets: the word area is [A0 + p, A0 + states); the ring holds [lo, wp) at least
-    const uint32_t A0 = c.src_off;
-    uint32_t wp = mine ? A0 + states : 0u, lo;
-    const uint32_t wbase = mine ? A0 + p : 0u;
+    // Offsets into the input, shifted by the parity of the word area's start so that every word sits at an even offset (one
+    // 16-bit LDS read a word): the word area is [wbase, wp0) of inq, the ring holds [lo, wp) at least
+    const uint32_t par = mine ? (c.src_off + p) & 1u : 0u;
+    const uint8_t *inq = in + par;
+    const uint32_t wbase = mine ? c.src_off + p - par : 0u;
+    uint32_t wp = mine ? c.src_off + states - par : 0u, lo;
     uint8_t *win = S.win[q];
     {
         const uint32_t target = wp > 512u ? (wp - 512u) & ~15u : 0u;
         const uint32_t top = (wp + 15u) & ~15u;
         if (mine)
-            for (uint32_t a = target + 16 * j; a < top; a += 256) *(uint4 *)(win + (a & (RANS_WIN - 1))) = load_u128_unaligned(in + a);
+            for (uint32_t a = target + 16 * j; a < top; a += 256) *(uint4 *)(win + (a & (RANS_WIN - 1))) = load_u128_unaligned(inq + a);
         lo = target;
     }
     rans_lds_order();
@@ -355,10 +406,12 @@ __device__ void rans_decode_group(RansDecLds &S, const uint8_t *in, const DecChu
         U = (mm + 255u) / 256u;
     }
     uint8_t *dst = arena + c.dst_off;
+    const uint32_t below = (1u << j) - 1u; // the coders of my chunk that take their words before me
 #pragma clang loop unroll(disable)
     for (uint32_t u = 0; u < U; u++) {
         const uint32_t off = u * 256u + j * 16u;
         const uint32_t have = (mine && off < m) ? (m - off < 16u ? m - off : 16u) : 0u;
+        const bool fast = __ballot(have == 16u) == ~0ull; // four chunks, every lane a whole unit: no per-lane conditions
         uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -367,24 +420,36 @@ __device__ void rans_decode_group(RansDecLds &S, const uint8_t *in, const DecChu
             uint4 fill = make_uint4(0u, 0u, 0u, 0u);
             const uint32_t fa = lo - 16u * (j + 1);
             const bool do_fill = mine && lo >= 16u * (j + 1) && fa >= target;
-            if (do_fill) fill = load_u128_unaligned(in + fa);
+            if (do_fill) fill = load_u128_unaligned(inq + fa);
+            if (fast) {
 #pragma unroll
-            for (int b8 = 0; b8 < 8; b8++) {
-                const int b = h * 8 + b8;
-                const uint32_t sl = x & 4095u;
-                const uint32_t s = S.slot[sl];
-                const uint32_t e = S.ft[s];
-                const bool act = (uint32_t)b < have;
-                const uint32_t xn = (e & 0xFFFFu) * (x >> 12) + sl - (e >> 16);
-                const bool need = act && xn < RANS_L;
-                const unsigned long long mask = __ballot(need);
-                const uint32_t seg = (uint32_t)(mask >> (16 * q)) & 0xFFFFu;
-                if (act) { x = xn; w[b >> 2] |= s << (8 * (b & 3)); }
-                if (need) {
-                    const uint32_t a = wp - 2u * ((uint32_t)__popc(seg & ((1u << j) - 1u)) + 1u);
-                    x = (x << 16) | (uint32_t)win[a & (RANS_WIN - 1)] | ((uint32_t)win[(a + 1) & (RANS_WIN - 1)] << 8);
+                for (int b8 = 0; b8 < 8; b8++) {
+                    const int b = h * 8 + b8;
+                    const uint32_t sl = x & 4095u;
+                    const uint32_t s = S.slot[sl];
+                    const uint32_t e = S.ft[s];
+                    x = __umul24(e & 0xFFFFu, x >> 12) + (sl - (e >> 16));
+                    w[b >> 2] |= s << (8 * (b & 3));
+                    const bool need = x < RANS_L;
+                    const uint32_t seg = (uint32_t)(__ballot(need) >> (16 * q)) & 0xFFFFu;
+                    if (need) x = (x << 16) | *(const uint16_t *)(win + ((wp - 2u * ((uint32_t)__popc(seg & below) + 1u)) & (RANS_WIN - 1)));
+                    wp -= 2u * (uint32_t)__popc(seg);
                 }
-                wp -= 2u * (uint32_t)__popc(seg);
+            } else {
+#pragma unroll
+                for (int b8 = 0; b8 < 8; b8++) {
+                    const int b = h * 8 + b8;
+                    const uint32_t sl = x & 4095u;
+                    const uint32_t s = S.slot[sl];
+                    const uint32_t e = S.ft[s];
+                    const bool act = (uint32_t)b < have;
+                    const uint32_t xn = __umul24(e & 0xFFFFu, x >> 12) + (sl - (e >> 16));
+                    const bool need = act && xn < RANS_L;
+                    const uint32_t seg = (uint32_t)(__ballot(need) >> (16 * q)) & 0xFFFFu;
+                    if (act) { x = xn; w[b >> 2] |= s << (8 * (b & 3)); }
+                    if (need) x = (x << 16) | *(const uint16_t *)(win + ((wp - 2u * ((uint32_t)__popc(seg & below) + 1u)) & (RANS_WIN - 1)));
+                    wp -= 2u * (uint32_t)__popc(seg);
+                }
             }
             if (mine && wp < wbase) { bad = true; wp = wbase; } // more words taken than the block holds: garbage, but in bounds
             if (do_fill) *(uint4 *)(win + (fa & (RANS_WIN - 1))) = fill;
