@@ -27,6 +27,7 @@ static void usage(FILE *f)
             "  -c          write to stdout (compress mode)\n"
             "  -b uint     records per block (default 100000)\n"
             "  -w int      compression workers (default: NumCPU; the GPU pipeline ignores it)\n"
+            "  -format n   container version to write: 2 (default, the reference's) or 3 (rANS-coded qualities; read by this tool only)\n"
             "  -version    show version and exit\n"
             "  -h          show help\n");
 }
@@ -99,6 +100,7 @@ int main(int argc, char **argv)
     std::string in_path, out_path;
     unsigned long block_size = FQZ_DEFAULT_BLOCK_SIZE;
     long workers = 0;
+    unsigned long format = 0;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -114,6 +116,7 @@ int main(int argc, char **argv)
         else if (a == "-o" || a == "--o") out_path = need("-o");
         else if (a == "-b" || a == "--b") block_size = strtoul(need("-b"), nullptr, 10);
         else if (a == "-w" || a == "--w") workers = strtol(need("-w"), nullptr, 10);
+        else if (a == "-format" || a == "--format") format = strtoul(need("-format"), nullptr, 10); // (not a flag of the reference: SURVEY 8 f-4 asks for version 3 "behind a flag")
         else if (a == "--") { for (int j = i + 1; j < argc; j++) pos.push_back(argv[j]); break; }
         else if (a.size() > 1 && a[0] == '-') { fprintf(stderr, "flag provided but not defined: %s\n", a.c_str()); usage(stderr); return 2; }
         else { for (int j = i; j < argc; j++) pos.push_back(argv[j]); break; } // Go's flag package stops at the first positional
@@ -155,7 +158,7 @@ int main(int argc, char **argv)
         fqz_decompress_options o = {(int32_t)workers};
         rc = fqz_decompress_stream(ctx, input_read, &in, output_write, fout, &o);
     } else {
-        fqz_options o = {(uint32_t)block_size, (int32_t)workers};
+        fqz_options o = {(uint32_t)block_size, (int32_t)workers, (uint32_t)format};
         rc = fqz_compress_stream(ctx, input_read, &in, output_write, fout, &o);
     }
     fqz_ctx_destroy(ctx);

@@ -23,6 +23,13 @@ def test_cli_round_trips(tmp_path, sample_fq):
     assert run(["-i", str(fq), "-o", str(fqz)]).returncode == 0
     assert run(["-d", "-i", str(fqz), "-o", str(out)]).returncode == 0
     assert out.read_bytes() == text
+    # -format 3: the version-3 container (rANS-coded qualities): smaller, same text back
+    fqz3, out3 = tmp_path / "r3.fqz", tmp_path / "r3.out"
+    assert run(["-format", "3", "-i", str(fq), "-o", str(fqz3)]).returncode == 0
+    assert fqz3.read_bytes()[4] == 3 and fqz3.stat().st_size < fqz.stat().st_size
+    assert run(["-d", "-i", str(fqz3), "-o", str(out3)]).returncode == 0
+    assert out3.read_bytes() == text
+    assert run(["-format", "7", "-i", str(fq), "-o", str(fqz3)]).returncode == 1
     # positionals, gzip input detected by suffix and by magic (main.go:142-174): same bytes as the plain input
     gz = tmp_path / "r.fq.gz"
     gz.write_bytes(gzip.compress(text))

@@ -88,7 +88,7 @@ def test_container_headers():
     assert O.lib().fqzo_write_block_header(C.byref(bh), 1, (C.c_uint8 * 32).from_buffer(out1)) == 32
     assert O.lib().fqzo_read_block_header(bytes(out1), 32, 1, C.byref(back)) == 32
     assert back.plus_size == 0 and back.npos_size == 10 and back.original_qual_size == 15001
-    assert O.lib().fqzo_write_block_header(C.byref(bh), 3, (C.c_uint8 * 36).from_buffer(out)) < 0
+    assert O.lib().fqzo_write_block_header(C.byref(bh), 4, (C.c_uint8 * 36).from_buffer(out)) < 0  # (3 is FQZ-R1: the version-2 header)
 
 
 def test_sample_fq_streams(sample_fq):
