@@ -1392,8 +1392,6 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         HIP_TRY(hipEventCreateWithFlags(&e.ev_join2, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithPriority(&e.side3, hipStreamNonBlocking, prio_hi));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_join3, hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&e.side4, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&e.ev_join4, hipEventDisableTiming));
     }
     static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: everything on one stream (standalone kernel times)
     // side: the entropy stage over the headers' literals; side2: the content checksums; side3: the headers' sequence sections
@@ -1404,14 +1402,12 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     const uint32_t hgroup_cap = hcap / FQZ_GROUP + e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + e.block_cap + 8 : group_cap;
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0)); // (the checksums need the streams only)
+    // container version 3: the qualities' rANS coder (a chain of short steps a wave) goes first on that stream, beside everything
+    // that follows; the checksums have slack until k_compact.  (A stream of its own bought nothing: HIP maps streams onto four
+    // hardware queues by default, and a fifth stream shares one - the kernel trace showed it queued behind k_xxh anyway.)
+    if (rmap) PROF(ctx, sd2, "k_rans", hipLaunchKernelGGL(k_rans, dim3(group_cap), dim3(64), 0, sd2, info, rmap, arena, slots, csize, getenv("FQZ_DBG_RANS") ? atoi(getenv("FQZ_DBG_RANS")) : 0));
     PROF(ctx, sd2, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd2, info, e.xmap.as<uint4>(), arena, npos, xsum));
     HIP_TRY(hipEventRecord(e.ev_join2, e.side2));
-    if (rmap) { // container version 3: the qualities' rANS coder, a chain of short steps a wave: beside everything that follows
-        const hipStream_t sd4 = dbg_serial ? st : e.side4;
-        HIP_TRY(hipStreamWaitEvent(e.side4, e.ev_fork, 0));
-        PROF(ctx, sd4, "k_rans", hipLaunchKernelGGL(k_rans, dim3(group_cap), dim3(64), 0, sd4, info, rmap, arena, slots, csize, getenv("FQZ_DBG_RANS") ? atoi(getenv("FQZ_DBG_RANS")) : 0));
-        HIP_TRY(hipEventRecord(e.ev_join4, e.side4));
-    }
     PROF(ctx, st, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, st, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside, hhist));
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side, e.ev_fork, 0));
@@ -1427,7 +1423,6 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join, 0));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join2, 0));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join3, 0));
-    if (rmap) HIP_TRY(hipStreamWaitEvent(st, e.ev_join4, 0));
     PROF(ctx, st, "k_hdr_patch", hipLaunchKernelGGL(k_hdr_patch, dim3(hcap), dim3(64), 0, st, info, hlist, hcap, hside, hsec, slots, csize));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap, hcap));
