@@ -35,6 +35,7 @@ def parse_args():
     ap.add_argument("--quality-profile", type=int, default=0)
     ap.add_argument("--container", type=int, default=2, help="container version the timed encode writes: 2 = the reference's (default), "
                     "3 = FQZ-R1 (rANS-coded qualities, SURVEY 8 f-4; not readable by the stock decoder)")
+    ap.add_argument("--no-v3", action="store_true", help="skip the supplementary container_v3 reading (profiling runs: one kind of launch per kernel)")
     ap.add_argument("--inflight", type=int, default=3, help="batches in flight for the supplementary pipelined figure (0 = skip)")
     return ap.parse_args()
 
@@ -346,7 +347,7 @@ def main():
             out["pipelined"] = {"error": repr(e)}
     # ---- supplementary: the same batch as a version-3 container (FQZ-R1, SURVEY 8 f-4: the qualities in interleaved rANS
     # blocks).  Not the headline: the stock decoder does not read it.
-    if a.container == 2 and world == 1 and len(batches) == 1:
+    if a.container == 2 and world == 1 and len(batches) == 1 and not a.no_v3:
         try:
             r3, d3 = BatchResult(), BatchResult()
             d_out3 = torch.empty_like(d_outs[0])

@@ -18,7 +18,7 @@ def fq():
     return fq
 
 
-def _encode_dev(fq, text_np, enc):
+def _encode_dev(fq, text_np, enc, version=2):
     import torch
     from fastqpacker_amd._lib import BatchResult, lib
     dev = torch.device("cuda:0")
@@ -28,13 +28,14 @@ def _encode_dev(fq, text_np, enc):
     res = BatchResult()
     nb = text_np.size // 200 // fq.DEFAULT_BLOCK_SIZE + 8
     offs, lens = (C.c_uint64 * nb)(), (C.c_uint64 * nb)()
-    fq._lib.check(lib().fqz_encode_batch_dev(ctx.handle, d_text.data_ptr(), text_np.size, fq.DEFAULT_BLOCK_SIZE, enc, fq.BATCH_FINAL,
+    fq._lib.check(lib().fqz_encode_batch_dev(ctx.handle, d_text.data_ptr(), text_np.size, fq.DEFAULT_BLOCK_SIZE, enc,
+                                             fq.BATCH_FINAL | (fq.BATCH_V3 if version == 3 else 0),
                                              d_out.data_ptr(), d_out.numel(), C.byref(res), offs, lens, nb, None))
     body = d_out[: int(res.out_len)].cpu().numpy()
     # and back on the device
     d_back = torch.empty(text_np.size + 4096, dtype=torch.uint8, device=dev)
     dres = BatchResult()
-    fq._lib.check(lib().fqz_decode_batch_dev(ctx.handle, d_out.data_ptr(), int(res.out_len), 2, enc, d_back.data_ptr(), d_back.numel(), C.byref(dres), None))
+    fq._lib.check(lib().fqz_decode_batch_dev(ctx.handle, d_out.data_ptr(), int(res.out_len), version, enc, d_back.data_ptr(), d_back.numel(), C.byref(dres), None))
     back_ok = bool(dres.out_len == text_np.size and torch.equal(d_back[: text_np.size], d_text))
     return body, res, list(lens[: res.n_blocks]), back_ok
 
@@ -59,6 +60,11 @@ def test_default_bench_batch_is_byte_identical_to_the_oracle(fq):
     assert want[9] == 0                                                   # Phred+33 detected by the oracle too
     assert body.size + 10 == want.size and np.array_equal(body, want[10:]), _first_diff(body, want[10:])
     assert sum(lens) == body.size
+    # the same batch as a version-3 container (FQZ-R1: rANS-coded qualities)
+    body3, res3, lens3, back3 = _encode_dev(fq, text, fq.ENCODING_PHRED33, version=3)
+    want3 = np.frombuffer(O.compress(text, workers=16, entropy=2), dtype=np.uint8)
+    assert back3 and want3[4] == 3 and np.array_equal(body3, want3[10:]), _first_diff(body3, want3[10:])
+    assert body3.size < 0.86 * body.size
 
 
 def test_config5_shape_ten_blocks_is_byte_identical_to_the_oracle(fq):
@@ -72,6 +78,9 @@ def test_config5_shape_ten_blocks_is_byte_identical_to_the_oracle(fq):
     assert want[9] == 2                                                   # FlagPhred64: the oracle detected Phred+64 on block 0
     assert np.array_equal(body, want[10:]), _first_diff(body, want[10:])
     assert bytes(O.decompress(want[:10].tobytes() + body.tobytes(), workers=16)) == text.tobytes()
+    body3, res3, lens3, back3 = _encode_dev(fq, text, fq.ENCODING_PHRED64, version=3)
+    want3 = np.frombuffer(O.compress(text, workers=16, entropy=2), dtype=np.uint8)
+    assert back3 and np.array_equal(body3, want3[10:]), _first_diff(body3, want3[10:])
 
 
 def test_sharded_path_with_the_hip_encoder_at_world_size_one(fq, tmp_path):

@@ -19,6 +19,14 @@ if stats:
     lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu --decode-steps 1 --inflight 0  (encode kernels: 1 warm-up + 5 timed + 3 per-kernel breakdown steps)")
     for r in csv.DictReader(open(stats[0])):
         lines.append("%-34s calls %5s total_ns %12s avg_ns %12s pct %6s" % (r.get("Name", "")[:34], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
+stats3 = sorted(glob.glob(src + "/trace_v3/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime, reverse=True)
+if stats3:
+    shutil.copy(stats3[0], os.path.join(dst, "rocprofv3_kernel_stats_bench_steps5_container_v3.csv"))
+    lines.append("")
+    lines.append("== the same command with --container 3 (FQZ-R1: rANS-coded qualities)")
+    for r in csv.DictReader(open(stats3[0])):
+        lines.append("%-34s calls %5s total_ns %12s avg_ns %12s pct %6s" % (r.get("Name", "")[:34], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
+    lines.append("")
 pmc = {}
 for tag, key in (("fetch", "FETCH_SIZE_KiB"), ("write", "WRITE_SIZE_KiB")):
     for f in sorted(glob.glob(src + "/pmc_%s/**/*counter_collection.csv" % tag, recursive=True), key=os.path.getmtime, reverse=True)[:1]:
