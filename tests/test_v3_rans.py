@@ -181,6 +181,16 @@ def test_gpu_v3_damage_is_an_error_never_wrong_text(fq):
 
 
 @pytest.mark.gpu
+def test_gpu_v3_block_level_entry_points(fq):
+    """fqz_decode_block / fqz_decode_block_size (decompressJobToPooledBuffer's replacement) take version 3 blocks as well"""
+    text = make_fastq(1500, seed=49, min_len=50, max_len=250)
+    z = O.compress(text, entropy=2)
+    assert fq.compress.decode_block(z[10:], version=3) == text
+    with pytest.raises(fq.FqzError):
+        fq.compress.decode_block(z[10:], version=2)  # reserved block type in a version-2 block
+
+
+@pytest.mark.gpu
 def test_gpu_v3_streaming_and_multi_device_paths(fq):
     text = make_fastq(30000, seed=48)
     want = O.compress(text, entropy=2)
