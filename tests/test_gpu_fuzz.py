@@ -31,14 +31,14 @@ def _cases():
     return out
 
 
-def _gpu_encode_blocks(fq, text, block, enc):
+def _gpu_encode_blocks(fq, text, block, enc, version=2):
     """device-resident batch encode with `block` records per block (the pipeline itself always batches 100 000)"""
     import torch
     dev = torch.device("cuda:0")
     t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev) if len(text) else torch.empty(0, dtype=torch.uint8, device=dev)
     out = torch.empty(fq.lib().fqz_encode_bound_blocks(len(text), block), dtype=torch.uint8, device=dev)
     res = fq.compress.encode_batch_dev(t.data_ptr() if len(text) else 0, len(text), out.data_ptr(), out.numel(), records_per_block=block,
-                                       qual_encoding=enc, final=True)
+                                       qual_encoding=enc, final=True, container_version=version)
     return out[: res.out_len].cpu().numpy().tobytes(), res
 
 
@@ -56,6 +56,11 @@ def test_random_shapes_match_oracle(fq, case):
     assert back == O.decompress(want)
     if not case["crlf"]:
         assert back == text  # {A,C,G,T,N} data round-trips exactly
+    # the same shape as a version-3 container (FQZ-R1: the qualities in rANS blocks)
+    want3 = O.compress(text, batch_records=block, entropy=2)
+    body3, res3 = _gpu_encode_blocks(fq, text, block, enc, version=3)
+    assert body3 == want3[10:]
+    assert fq.compress.Decompress(want3[:10] + body3) == back
 
 
 def test_long_reads_and_long_headers(fq):
