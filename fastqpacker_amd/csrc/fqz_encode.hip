@@ -847,10 +847,12 @@ __device__ __forceinline__ uint32_t h2_frame_hdr(uint32_t M) { return M < 256u ?
 // are Raw blocks by definition: their "compressed" size is known here and k_compact copies them straight from the arena.
 // cinfo[chunk] = block | stream << 24, for k_compact (which would otherwise repeat the search, one dependent load after another)
 __global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPlan *plans, uint4 *gmap, uint4 *hmap, uint4 *xmap, uint32_t group_cap, uint32_t *cinfo, uint32_t *csize,
-                                                   uint32_t *hord, uint32_t *hlist, uint32_t hcap, uint4 *rmap)
+                                                   uint32_t *hord, uint32_t *hlist, uint32_t hcap, uint4 *rmap, int part)
 {
-    const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
-    if (chunk >= info->n_chunks) return;
+    // part 0: the chunks of the main arena (known after k_plan1: the kernels that follow k_split need only these); part 1: the
+    // nPos chunks (after k_plan2); part 2: all
+    const uint32_t chunk = blockIdx.x * 256 + threadIdx.x + (part == 1 ? info->n_main : 0u);
+    if (chunk >= (part == 0 ? info->n_main : info->n_chunks)) return;
     uint32_t b, c;
     int s;
     locate_chunk(info, plans, chunk, &b, &s, &c);
@@ -1349,10 +1351,6 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
     }
     PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(256), 0, st, info, E, estride, plans, rpb, e.arena_cap, (uint32_t)main_cap));
-    PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
-    if ((rc = launch_scan(ctx, "scan_npos", st, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, z_npos))) return rc;
-    PROF(ctx, st, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, st, info, E, estride, plans, e.npos_cap, e.chunk_cap));
-    PROF(ctx, st, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, npos));
     const uint32_t group_cap = e.chunk_cap / FQZ_GROUP + FQZ_NS * e.block_cap + 8;
     if ((rc = e.gmap.ensure(48ull * group_cap))) return rc; // gmap | hmap | rmap
     if ((rc = e.xmap.ensure(16ull * group_cap + 4ull * (e.chunk_cap + 8)))) return rc;
@@ -1377,10 +1375,6 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     HdrSide *hside = (HdrSide *)(hsec + (size_t)hcap * HDR_SEQ_CAP);
     uint32_t *hlist = (uint32_t *)(hside + hcap);
     uint16_t *hhist = (uint16_t *)(hlist + hcap);
-    PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), hmap, e.xmap.as<uint4>(), group_cap,
-                                                    cinfo, csize, hord, hlist, hcap, rmap));
-    // the content checksums need the streams only: they are hashed on a side stream beside the entropy coder (a chain of
-    // memory round trips with a few waves per CU beside a kernel bound by instruction issue) and joined before k_compact
     if (!e.side) {
         // (the sequence sections are a chain of serial steps: with priority over the bulk entropy coders it is not the last to finish)
         int prio_lo = 0, prio_hi = 0;
@@ -1392,20 +1386,37 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         HIP_TRY(hipEventCreateWithFlags(&e.ev_join2, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithPriority(&e.side3, hipStreamNonBlocking, prio_hi));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_join3, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e.ev_npos, hipEventDisableTiming));
     }
     static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: everything on one stream (standalone kernel times)
-    // side: the entropy stage over the headers' literals; side2: the content checksums; side3: the headers' sequence sections
+    // side: the entropy stage over the headers' literals; side2: the rANS coder (version 3) and the content checksums; side3: the
+    // nPos chain, then the headers' sequence sections
     const hipStream_t sd = dbg_serial ? st : e.side, sd2 = dbg_serial ? st : e.side2, sd3 = dbg_serial ? st : e.side3;
+    // the group lists of the main arena's chunks need the plan only: they are ready before the split, so that what follows it -
+    // the headers model, the rANS coder - starts with the streams and not behind the nPos chain (scan, plan, write: ~70 us of
+    // small kernels on a nearly idle chip), which runs beside them
+    PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), hmap, e.xmap.as<uint4>(), group_cap,
+                                                    cinfo, csize, hord, hlist, hcap, rmap, 0));
+    PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
+    HIP_TRY(hipEventRecord(e.ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(e.side3, e.ev_fork, 0));
+    HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0));
+    if ((rc = launch_scan(ctx, "scan_npos", sd3, E + (size_t)S_NPOS * estride, &info->n_rec, 0, e.rec_cap, z_npos))) return rc;
+    PROF(ctx, sd3, "k_plan2", hipLaunchKernelGGL(k_plan2, dim3(1), dim3(256), 0, sd3, info, E, estride, plans, e.npos_cap, e.chunk_cap));
+    PROF(ctx, sd3, "k_npos_write", hipLaunchKernelGGL(k_npos_write, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, sd3, d_text, n, ls, info, E, estride, plans, rpb, npos));
+    PROF(ctx, sd3, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, sd3, info, plans, e.gmap.as<uint4>(), hmap, e.xmap.as<uint4>(), group_cap,
+                                                     cinfo, csize, hord, hlist, hcap, rmap, 1));
+    HIP_TRY(hipEventRecord(e.ev_npos, e.side3));
     // The headers model fills the chip like the entropy coder does (both are bound by instruction issue: side by side they
     // only take turns), so it runs in line; what follows it - the FSE state chains, the bit packing, the entropy stage over
     // the literals - is a chain of short, latency-bound kernels that runs beside the entropy coder of the other streams.
     const uint32_t hgroup_cap = hcap / FQZ_GROUP + e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + e.block_cap + 8 : group_cap;
-    HIP_TRY(hipEventRecord(e.ev_fork, st));
-    HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0)); // (the checksums need the streams only)
-    // container version 3: the qualities' rANS coder (a chain of short steps a wave) goes first on that stream, beside everything
-    // that follows; the checksums have slack until k_compact.  (A stream of its own bought nothing: HIP maps streams onto four
-    // hardware queues by default, and a fifth stream shares one - the kernel trace showed it queued behind k_xxh anyway.)
+    // container version 3: the qualities' rANS coder (a chain of short steps a wave) goes first on its stream, beside everything
+    // that follows; the content checksums - they need the streams only, nPos included - have slack until k_compact.  (A stream of
+    // its own for the coder bought nothing: HIP maps streams onto four hardware queues by default, and a fifth stream shares
+    // one - the kernel trace showed it queued behind k_xxh anyway.)
     if (rmap) PROF(ctx, sd2, "k_rans", hipLaunchKernelGGL(k_rans, dim3(group_cap), dim3(64), 0, sd2, info, rmap, arena, slots, csize, getenv("FQZ_DBG_RANS") ? atoi(getenv("FQZ_DBG_RANS")) : 0));
+    HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_npos, 0));
     PROF(ctx, sd2, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd2, info, e.xmap.as<uint4>(), arena, npos, xsum));
     HIP_TRY(hipEventRecord(e.ev_join2, e.side2));
     PROF(ctx, st, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model, dim3(hcap), dim3(256), 0, st, info, plans, cinfo, hlist, hcap, E + (size_t)S_HDR * estride, arena, hseq, hlit, hside, hhist));
@@ -1419,6 +1430,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     HIP_TRY(hipEventRecord(e.ev_join3, e.side3));
     PROF(ctx, sd, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, sd, info, hmap, arena, slots, csize, hord, hcap, hlit, hside, hhist));
     HIP_TRY(hipEventRecord(e.ev_join, e.side));
+    HIP_TRY(hipStreamWaitEvent(st, e.ev_npos, 0)); // (its list includes the nPos groups)
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), arena, npos, slots, csize, fqz_dbg_stop(), fqz_dbg_stamps(e)));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join, 0));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join2, 0));
@@ -1551,7 +1563,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     if ((rc = e.xmap.ensure(16ull * group_cap + 4ull * (chunks + 8)))) return rc;
     uint32_t *xsum = (uint32_t *)(e.xmap.as<uint4>() + group_cap);
     hipLaunchKernelGGL(k_group_map, dim3((chunks + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), (uint4 *)nullptr, e.xmap.as<uint4>(), group_cap, csize + chunks + 2, csize,
-                       (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint4 *)nullptr);
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint4 *)nullptr, 2);
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
     PROF(ctx, st, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, st, info, e.xmap.as<uint4>(), d_src, d_src, xsum));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;
