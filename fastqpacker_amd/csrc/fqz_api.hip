@@ -581,7 +581,8 @@ extern "C" int fqz_profile_enable(fqz_ctx *ctx, int on)
 {
     if (!ctx) return FQZ_E_ARG;
     ctx->prof.on = on != 0;
-    ctx->prof.dominant_only = on == 2;
+    ctx->prof.dominant_only = on == 2 || on == 3; // 2: k_entropy only, 3: k_rans only (container version 3)
+    ctx->prof.dominant = on == 3 ? "k_rans" : "k_entropy";
     return FQZ_OK;
 }
 extern "C" int fqz_profile_reset(fqz_ctx *ctx)

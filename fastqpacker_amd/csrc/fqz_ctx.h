@@ -126,7 +126,8 @@ struct ProfEntry { const char *name; hipEvent_t a, b; };
 struct ProfTotal { std::string name; double ms; uint32_t calls; };
 struct Prof {
     bool on = false;
-    bool dominant_only = false; // bracket only k_entropy (two events per batch instead of ~40: nothing to perturb the timed region)
+    bool dominant_only = false; // bracket only the dominant kernel (two events per batch instead of ~40: nothing to perturb the timed region)
+    const char *dominant = "k_entropy"; // (k_rans when the timed encode writes container version 3)
     bool armed = false;
     std::vector<ProfEntry> pending;
     std::vector<hipEvent_t> pool;
@@ -140,7 +141,7 @@ struct Prof {
     }
     void begin(const char *name, hipStream_t st)
     {
-        armed = on && (!dominant_only || !strcmp(name, "k_entropy"));
+        armed = on && (!dominant_only || !strcmp(name, dominant));
         if (!armed) return;
         ProfEntry e{name, get(), get()};
         (void)hipEventRecord(e.a, st);

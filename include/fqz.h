@@ -256,7 +256,7 @@ int fqz_decompress_file(fqz_ctx *ctx, const char *in_path, const char *out_path,
 /* When enabled, every kernel launch of the encode/decode pipelines is bracketed by
  * hipEventRecord on the stream it is launched on; fqz_profile_read accumulates the
  * elapsed times per kernel name since the last reset. */
-int fqz_profile_enable(fqz_ctx *ctx, int on); /* 0 off, 1 every kernel, 2 only the dominant encode kernel (k_entropy) */
+int fqz_profile_enable(fqz_ctx *ctx, int on); /* 0 off, 1 every kernel, 2 only the dominant encode kernel (k_entropy), 3 only k_rans (version 3) */
 int fqz_profile_reset(fqz_ctx *ctx);
 /* names: '\n'-separated kernel names (NUL-terminated); ms[i] total milliseconds, calls[i] launches. */
 int fqz_profile_read(fqz_ctx *ctx, char *names, size_t names_cap, double *ms, uint32_t *calls, size_t max_entries, size_t *n_entries);
