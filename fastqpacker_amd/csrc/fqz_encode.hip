@@ -1389,6 +1389,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         HIP_TRY(hipEventCreateWithFlags(&e.ev_npos, hipEventDisableTiming));
     }
     static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: everything on one stream (standalone kernel times)
+    static const int dbg_rans = getenv("FQZ_DBG_RANS") ? atoi(getenv("FQZ_DBG_RANS")) : 0;          // timing experiments on k_rans (garbage out)
     // side: the entropy stage over the headers' literals; side2: the rANS coder (version 3) and the content checksums; side3: the
     // nPos chain, then the headers' sequence sections
     const hipStream_t sd = dbg_serial ? st : e.side, sd2 = dbg_serial ? st : e.side2, sd3 = dbg_serial ? st : e.side3;
@@ -1415,7 +1416,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     // that follows; the content checksums - they need the streams only, nPos included - have slack until k_compact.  (A stream of
     // its own for the coder bought nothing: HIP maps streams onto four hardware queues by default, and a fifth stream shares
     // one - the kernel trace showed it queued behind k_xxh anyway.)
-    if (rmap) PROF(ctx, sd2, "k_rans", hipLaunchKernelGGL(k_rans, dim3(group_cap), dim3(64), 0, sd2, info, rmap, arena, slots, csize, getenv("FQZ_DBG_RANS") ? atoi(getenv("FQZ_DBG_RANS")) : 0));
+    if (rmap) PROF(ctx, sd2, "k_rans", hipLaunchKernelGGL(k_rans, dim3(group_cap), dim3(64), 0, sd2, info, rmap, arena, slots, csize, dbg_rans));
     HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_npos, 0));
     PROF(ctx, sd2, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd2, info, e.xmap.as<uint4>(), arena, npos, xsum));
     HIP_TRY(hipEventRecord(e.ev_join2, e.side2));
