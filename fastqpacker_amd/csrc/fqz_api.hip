@@ -101,7 +101,7 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     e.h_info.release(); e.h_plans.release();
     if (e.side) { (void)hipStreamSynchronize(e.side); (void)hipStreamDestroy(e.side); (void)hipEventDestroy(e.ev_fork); (void)hipEventDestroy(e.ev_join);
                   (void)hipStreamSynchronize(e.side2); (void)hipStreamDestroy(e.side2); (void)hipEventDestroy(e.ev_join2);
-                  (void)hipStreamSynchronize(e.side3); (void)hipStreamDestroy(e.side3); (void)hipEventDestroy(e.ev_join3); (void)hipEventDestroy(e.ev_npos); }
+                  (void)hipStreamSynchronize(e.side3); (void)hipStreamDestroy(e.side3); (void)hipEventDestroy(e.ev_join3); (void)hipEventDestroy(e.ev_npos); (void)hipEventDestroy(e.ev_gmap); }
     DecState &d = c->dec;
     DevBuf *db[] = {&d.info, &d.blocks, &d.chunks, &d.frames, &d.streams, &d.rec, &d.partials, &d.tables, &d.lz_scratch};
     for (DevBuf *b : db) b->release();

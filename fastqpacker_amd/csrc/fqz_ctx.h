@@ -67,7 +67,7 @@ struct EncState {
     hipStream_t side = nullptr;            // the headers chain (model, sequences, entropy) runs here beside the entropy coder of the other streams
     hipStream_t side2 = nullptr;           // the content checksums
     hipStream_t side3 = nullptr;           // the headers' Sequences_Sections (serial FSE state chains)
-    hipEvent_t ev_join2 = nullptr, ev_join3 = nullptr, ev_npos = nullptr;
+    hipEvent_t ev_join2 = nullptr, ev_join3 = nullptr, ev_npos = nullptr, ev_gmap = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool two_pass_now = false;   // the launch in flight used the two-pass index
     uint32_t two_pass_left = 0;  // > 0 after a batch overflowed a tile-local line slot: this many launches count newlines first, then index

@@ -1387,6 +1387,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
         HIP_TRY(hipStreamCreateWithPriority(&e.side3, hipStreamNonBlocking, prio_hi));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_join3, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e.ev_npos, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e.ev_gmap, hipEventDisableTiming));
     }
     static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: everything on one stream (standalone kernel times)
     static const int dbg_rans = getenv("FQZ_DBG_RANS") ? atoi(getenv("FQZ_DBG_RANS")) : 0;          // timing experiments on k_rans (garbage out)
@@ -1396,9 +1397,13 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     // the group lists of the main arena's chunks need the plan only: they are ready before the split, so that what follows it -
     // the headers model, the rANS coder - starts with the streams and not behind the nPos chain (scan, plan, write: ~70 us of
     // small kernels on a nearly idle chip), which runs beside them
-    PROF(ctx, st, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, st, info, plans, e.gmap.as<uint4>(), hmap, e.xmap.as<uint4>(), group_cap,
-                                                    cinfo, csize, hord, hlist, hcap, rmap, 0));
+    HIP_TRY(hipEventRecord(e.ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(e.side3, e.ev_fork, 0));
+    PROF(ctx, sd3, "k_group_map", hipLaunchKernelGGL(k_group_map, dim3((e.chunk_cap + 255) / 256), dim3(256), 0, sd3, info, plans, e.gmap.as<uint4>(), hmap, e.xmap.as<uint4>(), group_cap,
+                                                     cinfo, csize, hord, hlist, hcap, rmap, 0)); // (beside the split, which does not need them)
+    HIP_TRY(hipEventRecord(e.ev_gmap, e.side3));
     PROF(ctx, st, "k_split", hipLaunchKernelGGL(k_split, dim3(grid_for_waves((e.rec_cap + 63) / 64)), dim3(256), 0, st, d_text, n, ls, info, E, estride, plans, rpb, arena));
+    HIP_TRY(hipStreamWaitEvent(st, e.ev_gmap, 0));
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side3, e.ev_fork, 0));
     HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0));
