@@ -33,7 +33,7 @@ class BatchResult(C.Structure):
 class Options(C.Structure):
     """compress.Options (compress.go:74-77) + container_version (0 / 2: the reference's CurrentVersion; 3: FQZ-R1, rANS-coded
     qualities - SURVEY 8 f-4, not readable by the stock decoder)."""
-    _fields_ = [("block_size", C.c_uint32), ("workers", C.c_int32), ("container_version", C.c_uint32)]
+    _fields_ = [("block_size", C.c_uint32), ("workers", C.c_int32), ("container_version", C.c_uint32), ("block_index", C.c_uint32)]
 
 
 class DecompressOptions(C.Structure):
@@ -117,6 +117,7 @@ SIGNATURES = {
     "fqz_buffer_free": (None, [_vp]),
     "fqz_compress_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Options)]),
     "fqz_decompress_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, _vp, C.c_size_t, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(DecompressOptions)]),
+    "fqz_read_block_table": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t)]),
     "fqz_compress_file": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.POINTER(Options)]),
     "fqz_decompress_file": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.POINTER(DecompressOptions)]),
     "fqz_profile_enable": (C.c_int, [_vp, C.c_int]),

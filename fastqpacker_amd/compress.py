@@ -126,6 +126,17 @@ def encode_block(fastq, qual_encoding=0, ctx=None):
     return out[: n.value].tobytes(), nrec.value
 
 
+def read_block_table(fqz):
+    """[(offset of the block header in the file, records)] from the block table of a version-3 file written with
+    Options.block_index = 1 (include/fqz.h); raises FqzError if the file carries none.  Host only."""
+    a = _as_u8(fqz)
+    n = C.c_size_t(0)
+    check(lib().fqz_read_block_table(a.ctypes.data, a.size, None, None, 0, C.byref(n)))
+    off, rec = (C.c_uint64 * max(1, n.value))(), (C.c_uint32 * max(1, n.value))()
+    check(lib().fqz_read_block_table(a.ctypes.data, a.size, off, rec, n.value, C.byref(n)))
+    return [(int(off[i]), int(rec[i])) for i in range(n.value)]
+
+
 def decode_block(block, version=2, qual_encoding=0, ctx=None) -> bytes:
     """decompressJobToPooledBuffer (compress.go:780): block header + payloads -> FASTQ text."""
     ctx = ctx or default_ctx()

@@ -28,6 +28,7 @@ static void usage(FILE *f)
             "  -b uint     records per block (default 100000)\n"
             "  -w int      compression workers (default: NumCPU; the GPU pipeline ignores it)\n"
             "  -format n   container version to write: 2 (default, the reference's) or 3 (rANS-coded qualities; read by this tool only)\n"
+            "  -index      with -format 3: append a table of the blocks (offset, records) behind the last block\n"
             "  -version    show version and exit\n"
             "  -h          show help\n");
 }
@@ -101,6 +102,7 @@ int main(int argc, char **argv)
     unsigned long block_size = FQZ_DEFAULT_BLOCK_SIZE;
     long workers = 0;
     unsigned long format = 0;
+    bool index = false;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -116,6 +118,7 @@ int main(int argc, char **argv)
         else if (a == "-o" || a == "--o") out_path = need("-o");
         else if (a == "-b" || a == "--b") block_size = strtoul(need("-b"), nullptr, 10);
         else if (a == "-w" || a == "--w") workers = strtol(need("-w"), nullptr, 10);
+        else if (a == "-index" || a == "--index") index = true;
         else if (a == "-format" || a == "--format") format = strtoul(need("-format"), nullptr, 10); // (not a flag of the reference: SURVEY 8 f-4 asks for version 3 "behind a flag")
         else if (a == "--") { for (int j = i + 1; j < argc; j++) pos.push_back(argv[j]); break; }
         else if (a.size() > 1 && a[0] == '-') { fprintf(stderr, "flag provided but not defined: %s\n", a.c_str()); usage(stderr); return 2; }
@@ -158,7 +161,7 @@ int main(int argc, char **argv)
         fqz_decompress_options o = {(int32_t)workers};
         rc = fqz_decompress_stream(ctx, input_read, &in, output_write, fout, &o);
     } else {
-        fqz_options o = {(uint32_t)block_size, (int32_t)workers, (uint32_t)format};
+        fqz_options o = {(uint32_t)block_size, (int32_t)workers, (uint32_t)format, index ? 1u : 0u};
         rc = fqz_compress_stream(ctx, input_read, &in, output_write, fout, &o);
     }
     fqz_ctx_destroy(ctx);

@@ -81,6 +81,7 @@ __global__ void k_dec_blocks(const uint8_t *in, uint32_t n, uint32_t version, De
         const uint8_t *h = in + pos;
         uint32_t sz[FQZ_NS];
         uint32_t records = rd32(h);
+        if (version == FQZ_VERSION3 && records == FQZ_BLOCK_TABLE_MARK && rd32(h + 4) == 0x585A5146u) break; // 'FQZX': the block table, the chain ends here
         sz[S_SEQ] = rd32(h + 4); sz[S_QUAL] = rd32(h + 8); sz[S_HDR] = rd32(h + 12);
         if (version == FQZ_VERSION1) { sz[S_PLUS] = 0; sz[S_NPOS] = rd32(h + 16); sz[S_LEN] = rd32(h + 20); }
         else { sz[S_PLUS] = rd32(h + 16); sz[S_NPOS] = rd32(h + 20); sz[S_LEN] = rd32(h + 24); }

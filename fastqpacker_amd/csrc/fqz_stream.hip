@@ -158,14 +158,35 @@ void drain_loop(Pipe &P, Io &io, int device)
 struct ShardRole {
     int explicit_enc = -1;                 // >= 0: encode with this FQZ_ENCODING_*, write no file header
     std::function<void(int)> on_enc;       // the shard with block 0 reports what it detected
+    std::vector<std::pair<uint64_t, uint32_t>> *table = nullptr; // block table wanted: (offset in this shard's output, records) of its blocks
 };
+
+// block table of a version-3 file (include/fqz.h): appended behind the last block
+static void put_u32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; i++) v.push_back((uint8_t)(x >> (8 * i))); }
+static void put_u64(std::vector<uint8_t> &v, uint64_t x) { for (int i = 0; i < 8; i++) v.push_back((uint8_t)(x >> (8 * i))); }
+static std::vector<uint8_t> block_table_bytes(const std::vector<std::pair<uint64_t, uint32_t>> &t, uint64_t at)
+{
+    std::vector<uint8_t> v;
+    put_u32(v, FQZ_BLOCK_TABLE_MARK);
+    v.insert(v.end(), {'F', 'Q', 'Z', 'X'});
+    put_u32(v, (uint32_t)t.size());
+    for (const auto &e : t) { put_u64(v, e.first); put_u32(v, e.second); }
+    put_u64(v, at);
+    v.insert(v.end(), {'F', 'Q', 'Z', 'X'});
+    return v;
+}
+
 
 static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts, const ShardRole *role = nullptr)
 {
-    fqz_options o = {FQZ_DEFAULT_BLOCK_SIZE, 0, 0};                    // compress.go:126-128 (nil opts)
+    fqz_options o = {FQZ_DEFAULT_BLOCK_SIZE, 0, 0, 0};                  // compress.go:126-128 (nil opts)
     if (opts) o = *opts;
     if (o.container_version && o.container_version != FQZ_VERSION2 && o.container_version != FQZ_VERSION3) return FQZ_E_FILE_VERSION;
     const bool v3 = o.container_version == FQZ_VERSION3;
+    const bool want_table = o.block_index != 0;
+    if (want_table && !v3) return FQZ_E_ARG; // (a version-2 file is a plain chain of blocks: the stock reader would trip over a table)
+    std::vector<std::pair<uint64_t, uint32_t>> table_own, &table = (role && role->table) ? *role->table : table_own;
+    uint64_t out_pos = 0; // bytes this job has produced so far
     if (!o.block_size) o.block_size = FQZ_DEFAULT_BLOCK_SIZE;          // compress.go:129-131
     const uint32_t rpb = FQZ_DEFAULT_BLOCK_SIZE;                       // batches are always 100 000 records (compress.go:48-52, App. B-4)
     HIP_TRY(hipSetDevice(ctx->device));
@@ -233,9 +254,11 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts, const Sha
         const size_t cap = fqz_encode_bound_blocks(n_text, rpb);
         if ((rc = lane->d_out.ensure(cap + 64))) { P.fail(rc); break; }
         fqz_batch_result res;
+        std::vector<uint64_t> boff, blen;
+        if (want_table) { boff.resize(n_text / (6ull * rpb) + 2); blen.resize(boff.size()); } // (a record is at least six bytes)
         for (int attempt = 0;; attempt++) {
             rc = fqz_enc_launch(lane, d_text, n_text, rpb, enc, (final_batch ? FQZ_BATCH_FINAL : 0u) | (v3 ? FQZ_BATCH_V3 : 0u), lane->d_out.as<uint8_t>(), cap, lane->stream);
-            if (!rc) rc = fqz_enc_finish(lane, &res, nullptr, nullptr, 0);
+            if (!rc) rc = fqz_enc_finish(lane, &res, want_table ? boff.data() : nullptr, want_table ? blen.data() : nullptr, boff.size());
             if (rc == FQZ_E_TOO_LARGE && attempt < 3) continue; // the context has resized itself (very short lines): same launch again
             break;
         }
@@ -250,6 +273,11 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts, const Sha
             first = false;
             if (role && role->on_enc) role->on_enc(enc);
         }
+        if (s.header_first) out_pos += FQZ_FILE_HEADER_SIZE;
+        if (want_table)
+            for (uint32_t b = 0; b < res.n_blocks; b++)
+                table.emplace_back(out_pos + boff[b], b + 1 < res.n_blocks ? rpb : res.n_records - rpb * (res.n_blocks - 1));
+        out_pos += res.out_len;
         s.d_res = lane->d_out.as<uint8_t>();
         s.res_len = res.out_len;
         // what was not consumed (less than one block, unless nothing fitted: then the whole batch) opens the next batch
@@ -266,6 +294,18 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts, const Sha
     }
     feeder.join();
     drainer.join();
+    if (!P.err && want_table && !(role && role->table)) { // everything is out: the table goes behind the last block
+        const std::vector<uint8_t> t = block_table_bytes(table, out_pos);
+        if (io.count_only) io.written += t.size();
+        else if (io.mem_out) {
+            if (io.written + t.size() > io.mem_out_cap) return FQZ_E_DST_SMALL;
+            memcpy(io.mem_out + io.written, t.data(), t.size());
+            io.written += t.size();
+        } else {
+            if (io.wr(io.wr_user, t.data(), t.size())) return FQZ_E_IO;
+            io.written += t.size();
+        }
+    }
     return P.err;
 }
 
@@ -308,7 +348,9 @@ static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *op
             if (io.mem_in || !io.rd) { // walk the block headers in place, then one copy
                 const uint8_t *p = io.mem_in + io.mem_in_pos;
                 const size_t left = io.mem_in_n - io.mem_in_pos;
+                bool table = false;
                 while (n < left) {
+                    if (fh.version == FQZ_VERSION3 && left - n >= 8 && !memcmp(p + n, "\xFF\xFF\xFF\xFF" "FQZX", 8)) { table = true; break; } // the block table: the chain ends here
                     fqz_block_header bh;
                     int h = fqz_read_block_header(p + n, left - n, fh.version, &bh);
                     if (h < 0) { P.fail(h); return; }                   // "reading block header: unexpected EOF"
@@ -322,6 +364,7 @@ static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *op
                 if (s.d_new.ensure(n + 64)) { P.fail(FQZ_E_NOMEM); return; }
                 if (n && hipMemcpy(s.d_new.p, p, n, hipMemcpyHostToDevice) != hipSuccess) { P.fail(FQZ_E_HIP); return; }
                 io.mem_in_pos += n;
+                if (table) io.mem_in_pos = io.mem_in_n;
                 eof = io.mem_in_pos == io.mem_in_n;
             } else {
                 size_t cap = slice + (64u << 20);
@@ -336,6 +379,7 @@ static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *op
                         if (r == 0) { eof = true; break; }              // clean EOF at a block boundary (compress.go:614-617)
                         if ((uint32_t)r < hs) { P.fail(FQZ_E_SHORT); return; }
                     }
+                    if (fh.version == FQZ_VERSION3 && !memcmp(bhb, "\xFF\xFF\xFF\xFF" "FQZX", 8)) { eof = true; break; } // the block table: the chain ends here (the rest is not read)
                     fqz_block_header bh;
                     (void)fqz_read_block_header(bhb, hs, fh.version, &bh);
                     const unsigned long long pay = (unsigned long long)bh.seq_size + bh.qual_size + bh.header_size + bh.plus_size + bh.npos_size + bh.lengths_size;
@@ -563,6 +607,7 @@ struct Shard {
     unsigned long long lines = 0;
     size_t a = 0, b = 0;               // the shard: text bytes [a, b), whole blocks
     std::vector<uint8_t> out;
+    std::vector<std::pair<uint64_t, uint32_t>> table; // its blocks: (offset in `out`, records)
     int rc = 0;
 };
 
@@ -581,6 +626,8 @@ extern "C" int fqz_compress_multi(const int *devices, int n_devices, const uint8
     *out_len = 0;
     const uint32_t rpb = FQZ_DEFAULT_BLOCK_SIZE;
     const int N = n_devices;
+    const bool want_table = opts && opts->block_index;
+    if (want_table && opts->container_version != FQZ_VERSION3) return FQZ_E_ARG;
     std::vector<Shard> sh((size_t)N);
     // byte ranges: equal parts, cut at multiples of the counting tile
     for (int d = 0; d < N; d++) {
@@ -658,6 +705,7 @@ extern "C" int fqz_compress_multi(const int *devices, int n_devices, const uint8
                 Shard &s = sh[d];
                 (void)hipSetDevice(s.device);
                 ShardRole role;
+                if (want_table) role.table = &s.table;
                 if (d == 0) role.on_enc = [&](int e) { std::lock_guard<std::mutex> g(mu); file_enc = e; cv.notify_all(); };
                 else {
                     std::unique_lock<std::mutex> g(mu);
@@ -689,11 +737,18 @@ extern "C" int fqz_compress_multi(const int *devices, int n_devices, const uint8
         }
     if (rc) return rc;
     size_t total = 0;
-    for (int d = 0; d < N; d++) total += sh[d].out.size();
-    if (total > out_cap) return FQZ_E_DST_SMALL;
+    std::vector<std::pair<uint64_t, uint32_t>> table;
+    for (int d = 0; d < N; d++) {
+        for (const auto &e : sh[d].table) table.emplace_back(total + e.first, e.second); // (offsets in the shard's output -> in the file)
+        total += sh[d].out.size();
+    }
+    std::vector<uint8_t> tb;
+    if (want_table) tb = block_table_bytes(table, total);
+    if (total + tb.size() > out_cap) return FQZ_E_DST_SMALL;
     size_t pos = 0;
     for (int d = 0; d < N; d++) { if (!sh[d].out.empty()) memcpy(out + pos, sh[d].out.data(), sh[d].out.size()); pos += sh[d].out.size(); }
-    *out_len = total;
+    if (!tb.empty()) memcpy(out + pos, tb.data(), tb.size());
+    *out_len = total + tb.size();
     return FQZ_OK;
 }
 
@@ -712,7 +767,9 @@ extern "C" int fqz_decompress_multi(const int *devices, int n_devices, const uin
     // block boundaries
     std::vector<size_t> starts;
     size_t pos = FQZ_FILE_HEADER_SIZE;
+    size_t body_end = n; // (a version-3 file may end with its block table: the blocks end in front of it)
     while (pos < n) {
+        if (fh.version == FQZ_VERSION3 && n - pos >= 8 && !memcmp(fqz + pos, "\xFF\xFF\xFF\xFF" "FQZX", 8)) { body_end = pos; break; }
         fqz_block_header bh;
         const int h = fqz_read_block_header(fqz + pos, n - pos, fh.version, &bh);
         if (h < 0) return h;
@@ -721,7 +778,7 @@ extern "C" int fqz_decompress_multi(const int *devices, int n_devices, const uin
         starts.push_back(pos);
         pos += (size_t)h + (size_t)pay;
     }
-    starts.push_back(n);
+    starts.push_back(body_end);
     const size_t nblk = starts.size() - 1;
     const int N = n_devices;
     struct DShard { size_t a = 0, b = 0; fqz_ctx *ctx = nullptr; std::vector<uint8_t> out; int rc = 0; };
@@ -733,7 +790,7 @@ extern "C" int fqz_decompress_multi(const int *devices, int n_devices, const uin
             sh[d].a = starts[k];
             if (d + 1 == N) k = nblk;
             else {
-                const size_t want = FQZ_FILE_HEADER_SIZE + (size_t)((unsigned long long)(n - FQZ_FILE_HEADER_SIZE) * (unsigned)(d + 1) / (unsigned)N);
+                const size_t want = FQZ_FILE_HEADER_SIZE + (size_t)((unsigned long long)(body_end - FQZ_FILE_HEADER_SIZE) * (unsigned)(d + 1) / (unsigned)N);
                 while (k < nblk && starts[k + 1] <= want) k++;
             }
             sh[d].b = starts[k];
@@ -762,5 +819,32 @@ extern "C" int fqz_decompress_multi(const int *devices, int n_devices, const uin
     size_t at = 0;
     for (int d = 0; d < N; d++) { if (!sh[d].out.empty()) memcpy(buf + at, sh[d].out.data(), sh[d].out.size()); at += sh[d].out.size(); }
     *out = buf; *out_len = total;
+    return FQZ_OK;
+}
+
+// The block table of a version-3 file (include/fqz.h), read from the end of the file.  Host only.
+extern "C" int fqz_read_block_table(const uint8_t *fqz, size_t n, uint64_t *off, uint32_t *n_records, size_t cap, size_t *n_blocks)
+{
+    if (!fqz || !n_blocks) return FQZ_E_ARG;
+    *n_blocks = 0;
+    fqz_file_header fh;
+    int rc = fqz_read_file_header(fqz, n, &fh);
+    if (rc) return rc;
+    auto u32 = [&](size_t p) { return (uint32_t)fqz[p] | ((uint32_t)fqz[p + 1] << 8) | ((uint32_t)fqz[p + 2] << 16) | ((uint32_t)fqz[p + 3] << 24); };
+    auto u64 = [&](size_t p) { return (uint64_t)u32(p) | ((uint64_t)u32(p + 4) << 32); };
+    if (fh.version != FQZ_VERSION3 || n < FQZ_FILE_HEADER_SIZE + 24 || memcmp(fqz + n - 4, "FQZX", 4)) return FQZ_E_ARG;
+    const uint64_t at = u64(n - 12);
+    if (at < FQZ_FILE_HEADER_SIZE || at > n - 24 || u32((size_t)at) != FQZ_BLOCK_TABLE_MARK || memcmp(fqz + at + 4, "FQZX", 4)) return FQZ_E_ARG;
+    const uint32_t nb = u32((size_t)at + 8);
+    if ((uint64_t)nb * 12 + 24 != n - at) return FQZ_E_ARG;
+    *n_blocks = nb;
+    if (!off && !n_records) return FQZ_OK;
+    if (nb > cap) return FQZ_E_DST_SMALL;
+    for (uint32_t b = 0; b < nb; b++) {
+        const uint64_t o = u64((size_t)at + 12 + 12ull * b);
+        if (o < FQZ_FILE_HEADER_SIZE || o + 36 > at) return FQZ_E_ARG; // (every entry points at a block header in front of the table)
+        if (off) off[b] = o;
+        if (n_records) n_records[b] = u32((size_t)at + 12 + 12ull * b + 8);
+    }
     return FQZ_OK;
 }

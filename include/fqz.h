@@ -215,7 +215,17 @@ typedef struct {          /* compress.Options compress.go:74-77 */
     uint32_t block_size;  /* BlockSize: written to the file header only; 0 -> 100000 */
     int32_t  workers;     /* Workers: kept for API parity; the GPU pipeline sizes itself. 0 -> default */
     uint32_t container_version; /* 0 or 2: CurrentVersion (container.go:24); 3: FQZ_VERSION3 */
+    uint32_t block_index;       /* version 3 only: 1 = append the block table (below) behind the last block */
 } fqz_options;
+
+/* Block table of a version-3 file ("optional on-disk block index"; not a reference format).  Behind the last
+ * block:  u32 0xFFFFFFFF (where a block header's NumRecords would stand: never a valid count) | 'FQZX' | u32 n_blocks |
+ * n_blocks x { u64 offset of the block header from the start of the file, u32 NumRecords } | u64 offset of the table | 'FQZX'.
+ * Readers of the block chain stop at it; a reader with random access finds it from the end of the file.
+ * fqz_read_block_table: host only, no device work.  off / n_records may be NULL (only *n_blocks is wanted); FQZ_E_DST_SMALL
+ * if cap is too small; FQZ_E_ARG if the file carries no table. */
+#define FQZ_BLOCK_TABLE_MARK 0xFFFFFFFFu
+int fqz_read_block_table(const uint8_t *fqz, size_t n, uint64_t *off, uint32_t *n_records, size_t cap, size_t *n_blocks);
 typedef struct {          /* compress.DecompressOptions compress.go:80-82 */
     int32_t workers;
 } fqz_decompress_options;

@@ -552,8 +552,9 @@ static int resolve_workers(int w)
 
 long fqzo_compress(const uint8_t *fastq, size_t n, uint8_t *out, size_t cap, const fqzo_options *opt)
 {
-    fqzo_options o = {0, 0, 0, 0, 0};
+    fqzo_options o = {0, 0, 0, 0, 0, 0};
     if (opt) o = *opt;
+    if (o.block_index && o.entropy != 2) return FQZO_E_FILE_VERSION;
     if (!o.block_size) o.block_size = 100000;       /* compress.go:126-131 */
     if (!o.batch_records) o.batch_records = 100000; /* compress.go:48-52: batches are always 100 000 records (App. B-4) */
     int workers = resolve_workers(o.workers);
@@ -598,7 +599,16 @@ long fqzo_compress(const uint8_t *fastq, size_t n, uint8_t *out, size_t cap, con
     size_t w = 10;
 
     size_t n_jobs = (n_rec + o.batch_records - 1) / o.batch_records;
-    if (!n_jobs) { free(recs); return (long)w; } /* App. B-7: empty input -> header only */
+    if (!n_jobs) { /* App. B-7: empty input -> header only (and an empty block table when one is asked for) */
+        free(recs);
+        if (o.block_index) {
+            if (cap < w + 24) return FQZO_E_DST_SMALL;
+            memset(out + w, 0xFF, 4); memcpy(out + w + 4, "FQZX", 4); memset(out + w + 8, 0, 4);
+            memset(out + w + 12, 0, 8); out[w + 12] = (uint8_t)w; memcpy(out + w + 20, "FQZX", 4);
+            w += 24;
+        }
+        return (long)w;
+    }
     enc_job *jobs = calloc(n_jobs, sizeof *jobs);
     if (!jobs) { free(recs); return FQZO_E_NOMEM; }
     for (size_t b = 0; b < n_jobs; b++) {
@@ -627,6 +637,26 @@ long fqzo_compress(const uint8_t *fastq, size_t n, uint8_t *out, size_t cap, con
             else { memcpy(out + w, jobs[b].out, jobs[b].out_len); w += jobs[b].out_len; }
         }
         free(jobs[b].out);
+    }
+    if (!ret && o.block_index) { /* block table: mark | 'FQZX' | n | n x { u64 offset, u32 records } | u64 offset of the table | 'FQZX' */
+        const size_t need = 12 + 12 * n_jobs + 12;
+        if (w + need > cap) ret = FQZO_E_DST_SMALL;
+        else {
+            uint8_t *t = out + w;
+            const uint64_t at = w;
+            uint64_t off = 10;
+            memset(t, 0xFF, 4); memcpy(t + 4, "FQZX", 4);
+            for (int i = 0; i < 4; i++) t[8 + i] = (uint8_t)(n_jobs >> (8 * i));
+            t += 12;
+            for (size_t b = 0; b < n_jobs; b++, t += 12) {
+                for (int i = 0; i < 8; i++) t[i] = (uint8_t)(off >> (8 * i));
+                for (int i = 0; i < 4; i++) t[8 + i] = (uint8_t)((uint32_t)jobs[b].n_rec >> (8 * i));
+                off += jobs[b].out_len;
+            }
+            for (int i = 0; i < 8; i++) t[i] = (uint8_t)(at >> (8 * i));
+            memcpy(t + 8, "FQZX", 4);
+            w += need;
+        }
     }
     free(jobs);
     free(recs);
@@ -741,6 +771,7 @@ long fqzo_decompress(const uint8_t *fqz, size_t n, uint8_t *out, size_t cap, int
     dec_job *jobs = malloc(cap_jobs * sizeof *jobs);
     if (!jobs) return FQZO_E_NOMEM;
     while (pos < n) { /* clean EOF only at a block-header boundary, compress.go:614-617 */
+        if (fh.version == 3 && n - pos >= 8 && !memcmp(fqz + pos, "\xFF\xFF\xFF\xFF" "FQZX", 8)) break; /* FQZ-R1's block table: the chain ends here */
         fqzo_block_header bh;
         int hs = fqzo_read_block_header(fqz + pos, n - pos, fh.version, &bh);
         if (hs < 0) { free(jobs); return hs; } /* "reading block header: unexpected EOF" */

@@ -189,6 +189,8 @@ typedef struct {
                              * 2 = container version 3 (FQZ-R1: FQZ-H2 with rANS-coded qualities) */
     int force_encoding;     /* 0 = DetectEncoding on the first batch (compress.go:146-154); 1 = Phred+33, 2 = Phred+64: a shard of a
                              * file whose first batch another process saw (multi-GPU sharding: rank 0 detects and broadcasts) */
+    int block_index;        /* entropy == 2 only: 1 = append the block table behind the last block (include/fqz.h: FQZ-R1's optional
+                             * on-disk block index) */
 } fqzo_options;
 
 size_t fqzo_compress_bound(size_t n_bytes);

@@ -30,6 +30,13 @@ def test_cli_round_trips(tmp_path, sample_fq):
     assert run(["-d", "-i", str(fqz3), "-o", str(out3)]).returncode == 0
     assert out3.read_bytes() == text
     assert run(["-format", "7", "-i", str(fq), "-o", str(fqz3)]).returncode == 1
+    # -index: the block table behind the last block; the decompressor stops at it
+    fqz4, out4 = tmp_path / "r4.fqz", tmp_path / "r4.out"
+    assert run(["-format", "3", "-index", "-i", str(fq), "-o", str(fqz4)]).returncode == 0
+    assert fqz4.read_bytes()[-4:] == b"FQZX" and fqz4.read_bytes()[4] == 3
+    assert run(["-d", "-i", str(fqz4), "-o", str(out4)]).returncode == 0
+    assert out4.read_bytes() == text
+    assert run(["-index", "-i", str(fq), "-o", str(fqz4)]).returncode == 1  # (version 2 carries no table)
     # positionals, gzip input detected by suffix and by magic (main.go:142-174): same bytes as the plain input
     gz = tmp_path / "r.fq.gz"
     gz.write_bytes(gzip.compress(text))

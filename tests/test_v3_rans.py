@@ -180,6 +180,64 @@ def test_gpu_v3_damage_is_an_error_never_wrong_text(fq):
         fq.compress.Compress(text, fq.Options(0, 0, 4))
 
 
+def _table(z):
+    """the block table parsed by hand: [(offset, records)], offset of the table"""
+    assert z[-4:] == b"FQZX"
+    at = int.from_bytes(z[-12:-4], "little")
+    assert z[at:at + 8] == b"\xff\xff\xff\xffFQZX"
+    nb = int.from_bytes(z[at + 8:at + 12], "little")
+    assert at + 12 + 12 * nb + 12 == len(z)
+    return [(int.from_bytes(z[at + 12 + 12 * b:at + 20 + 12 * b], "little"), int.from_bytes(z[at + 20 + 12 * b:at + 24 + 12 * b], "little")) for b in range(nb)], at
+
+
+def test_oracle_v3_block_table():
+    """FQZ-R1's optional on-disk block index: behind the last block, found from the end of the file, and the
+    readers of the block chain stop at it"""
+    text = make_fastq(2500, seed=50, min_len=40, max_len=120)
+    plain = O.compress(text, batch_records=700, entropy=2)
+    z = O.compress(text, batch_records=700, entropy=2, block_index=1)
+    table, at = _table(z)
+    assert z[:at] == plain and [r for _, r in table] == [700, 700, 700, 400]
+    for off, rec in table:
+        assert int.from_bytes(z[off:off + 4], "little") == rec  # a block header stands there
+    assert O.decompress(z) == text
+    assert _table(O.compress(b"", entropy=2, block_index=1))[0] == []
+    with pytest.raises(O.OracleError):
+        O.compress(text, block_index=1)  # version 2 is a plain chain of blocks: the stock reader would trip over a table
+
+
+@pytest.mark.gpu
+def test_gpu_v3_block_table(fq):
+    text = make_fastq(230000, seed=51, min_len=30, max_len=50)  # three blocks of 100 000 records
+    opts = fq.Options(0, 0, 3, 1)
+    z = fq.compress.Compress(text, opts)
+    assert z == O.compress(text, entropy=2, block_index=1)
+    table = fq.compress.read_block_table(z)
+    assert table == _table(z)[0] and [r for _, r in table] == [100000, 100000, 30000]
+    assert fq.compress.Decompress(z) == text                          # the memory reader stops at the table
+    assert fq.compress.DecompressMulti(z, [0, 0]) == text             # so does the walk that shares the blocks out
+    assert fq.compress.CompressMulti(text, [0, 0, 0], opts) == z      # several devices: one table for the file
+    # random access: a block decoded on its own from its offset
+    ends = [o for o, _ in table[1:]] + [_table(z)[1]]
+    parts = [fq.compress.decode_block(z[o:e], version=3) for (o, _), e in zip(table, ends)]
+    assert b"".join(parts) == text
+    # the streaming reader (callbacks) stops at the table as well
+    import io
+    out = io.BytesIO()
+    fq.compress.DecompressStream(io.BytesIO(z), out)
+    assert out.getvalue() == text
+    # no table: asking for one is an error, and so is a table in a version-2 file
+    with pytest.raises(fq.FqzError):
+        fq.compress.read_block_table(fq.compress.Compress(text, _v3(fq)))
+    with pytest.raises(fq.FqzError):
+        fq.compress.Compress(text, fq.Options(0, 0, 2, 1))
+    # a damaged table is refused by the lookup, the blocks are still read
+    bad = bytearray(z)
+    bad[-8] ^= 0x40
+    with pytest.raises(fq.FqzError):
+        fq.compress.read_block_table(bytes(bad))
+
+
 @pytest.mark.gpu
 def test_gpu_v3_block_level_entry_points(fq):
     """fqz_decode_block / fqz_decode_block_size (decompressJobToPooledBuffer's replacement) take version 3 blocks as well"""
