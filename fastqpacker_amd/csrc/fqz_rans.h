@@ -13,7 +13,6 @@
 #include "fqz_internal.h"
 
 #define RANS_L 65536u
-#define RANS_LANES 16u
 
 __device__ __forceinline__ void rans_lds_order()
 {
@@ -288,7 +287,6 @@ struct RansDecLds {
     uint32_t ft[256];     // symbol -> f | cum << 16
     uint8_t esym[256];    // table entry -> symbol
     uint8_t win[4][RANS_WIN];
-    uint32_t fail;
 };
 
 // One wave per group that has rANS blocks.  gd.x: id of the group's first chunk, gd.y: chunks in the group | index of the
@@ -311,7 +309,6 @@ __device__ void rans_decode_group(RansDecLds &S, const uint8_t *in, const DecChu
     if (bad) { *failed = true; return; }
 #pragma unroll
     for (int p = 0; p < 4; p++) { S.ft[lane + 64 * p] = 0; ((uint4 *)S.slot)[lane + 64 * p] = make_uint4(0u, 0u, 0u, 0u); }
-    if (lane == 0) S.fail = 0;
     __syncthreads();
     {
         uint32_t cum_carry = 0, prev_sym_carry = 0xFFFFFFFFu;
