@@ -37,7 +37,77 @@ def parse_args():
                     "3 = FQZ-R1 (rANS-coded qualities, SURVEY 8 f-4; not readable by the stock decoder)")
     ap.add_argument("--no-v3", action="store_true", help="skip the supplementary container_v3 reading (profiling runs: one kind of launch per kernel)")
     ap.add_argument("--inflight", type=int, default=3, help="batches in flight for the supplementary pipelined figure (0 = skip)")
+    ap.add_argument("--dry-ranks", action="store_true", help="CPU rehearsal of the N-rank path (gloo, no GPU, no codec): every rank runs the "
+                    "launcher, the rendezvous, the block-offset all-gather and the max-over-ranks timing on made-up block sizes")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """`bench.py --gpus N` (N > 1) outside a torchrun job: start N ranks, one per GPU, and relay rank 0's JSON line.  This process
+    never imports torch.cuda or libfqzhip and never touches a device; the ranks are children of the launcher child
+    (`python -m torch.distributed.run`), nothing re-execs a process that has initialised the GPU.  Stands where the reference
+    starts its worker pool (internal/compress/compress.go:240-278); the ordered collector (:365-403) is the offset exchange."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    return p.returncode if p.returncode else (0 if line else 1)
+
+
+def dry_ranks(a, rank, world):
+    """--dry-ranks: the N-rank control path on CPU (gloo).  No codec runs, so the line carries no throughput."""
+    import torch
+    import torch.distributed as dist
+    from fastqpacker_amd import sharding
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    enc = sharding.broadcast_encoding(1 if rank == 0 else 0, src=0)       # rank 0 "detected" Phred+64
+    lens = [1000 + 13 * rank + k for k in range(3 + rank)]                # made-up compressed block sizes
+    ex = sharding.OffsetExchange(8, world, device=None)
+    for _ in range(a.warmup):
+        ex.run(lens)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        offs, total = ex.run(lens)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    want_total = 10 + sum(1000 + 13 * r + k for r in range(world) for k in range(3 + r))
+    want_first = 10 + sum(1000 + 13 * r + k for r in range(rank) for k in range(3 + r))
+    ok = torch.tensor([1 if (total == want_total and offs[0] == want_first and enc == 1) else 0], dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"metric": "encode MB/s (input FASTQ), 150 bp Illumina", "value": None, "unit": "MB/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": round(float(tt.item()) / max(1, a.steps) * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "none",
+                          "config": {"workload": "dry ranks: launcher + gloo rendezvous + block-offset exchange on made-up sizes; no codec, no GPU"},
+                          "dry_ranks": True, "sharded_file_layout_ok": bool(ok.item())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def cpu_baseline(text_np, want_seconds=20.0):
@@ -96,9 +166,13 @@ def cpu_baseline(text_np, want_seconds=20.0):
 
 def main():
     a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))  # (before anything in this process imports torch.cuda or loads libfqzhip)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.dry_ranks:
+        return dry_ranks(a, rank, world)
     import torch  # device memory, streams and torch.distributed only; imported before libfqzhip so both share one HIP runtime
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -154,6 +228,8 @@ def main():
     lens = [(C.c_uint64 * max_blocks)() for _ in batches]
     ress = [BatchResult() for _ in batches]
     world_blocks = max_blocks * len(batches)
+    exch = sharding.OffsetExchange(world_blocks, world, device=dev) if world > 1 else None
+    lens_np = [np.ctypeslib.as_array(l) for l in lens]
 
     def encode_step():
         for i, b in enumerate(batches):
@@ -163,8 +239,10 @@ def main():
         if world > 1:
             # container index: all-gather of per-block compressed sizes -> exclusive prefix = file offsets (RCCL over xGMI);
             # the function the world-size-2 gloo test covers
-            mine = [int(x) for i in range(len(batches)) for x in lens[i][: ress[i].n_blocks]]
-            return sharding.block_offsets_allgather(mine, world_blocks, device=dev)
+            at = 0
+            for i in range(len(batches)):
+                at = exch.fill(lens_np[i][: ress[i].n_blocks], at)
+            return exch.exchange()  # device tensors: nothing here allocates or waits for the host
         return None
 
     for _ in range(a.warmup):
@@ -213,6 +291,7 @@ def main():
     sharded_ok = None
     if world > 1:
         my_offs, file_total, allsz = placed
+        my_offs, file_total = my_offs.tolist(), int(file_total.item())
         mine = [int(x) for i in range(len(batches)) for x in lens[i][: ress[i].n_blocks]]
         ok = int(file_total) == int(total_out) + 10 and len(my_offs) == len(mine)
         flat = allsz.reshape(-1).tolist()
@@ -240,12 +319,16 @@ def main():
         decode_step()
         roundtrip_ok = all(bool(dress[i].out_len == batches[i].size and torch.equal(d_backs[i][: batches[i].size], d_texts[i]))
                            for i in range(len(batches)))
-        torch.cuda.synchronize()
         if a.profile:
             ctx.profile(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(a.decode_steps):
             decode_step()
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
         ddt = (time.perf_counter() - t1) / max(1, a.decode_steps)
         dkern = ctx.profile_read() if a.profile else {}
@@ -253,6 +336,13 @@ def main():
     except fq.FqzError as e:  # only reachable in the FQZ_DBG_STOP timing experiments (garbage blocks)
         roundtrip_ok, ddt, dkern = False, float("inf"), {}
         print("decode failed: %s" % e, file=sys.stderr)
+    if world > 1:  # whole-job decode figure: every rank's shard, the slowest rank's time; the round trip must hold on every rank
+        dd = torch.tensor([ddt if ddt != float("inf") else 1e30], dtype=torch.float64, device=dev)
+        dist.all_reduce(dd, op=dist.ReduceOp.MAX)
+        ddt = float(dd.item())
+        rt = torch.tensor([1 if roundtrip_ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(rt, op=dist.ReduceOp.MIN)
+        roundtrip_ok = bool(rt.item())
 
     if rank != 0:
         if world > 1:
@@ -297,7 +387,7 @@ def main():
         "config": {"workload": workload, "bytes_per_gpu": in_bytes, "records_per_gpu": n_records, "blocks_per_gpu": n_blocks,
                    "device_batches_per_step": launches_per_step},
         "ratio": round(total_in / total_out, 3),
-        "decode_MBps": round(in_bytes / ddt / 1e6, 1), "roundtrip_bit_exact": roundtrip_ok,
+        "decode_MBps": round(total_in / ddt / 1e6, 1), "roundtrip_bit_exact": roundtrip_ok,
         "input_frac_of_hbm_peak": round(total_in / dt * a.steps / 1e9 / (HBM_PEAK_GBS * world), 4),
         "roofline": roof, "kernel_ms": kernels,
         "decode_kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in dkern.items()},

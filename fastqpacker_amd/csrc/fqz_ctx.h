@@ -86,6 +86,7 @@ struct EncState {
     DevBuf hside;     // headers model: sequences | literals | Sequences_Sections | HdrSide | chunk list (fqz_hdrlz.h)
     uint32_t plans_pre = 0;           // block plans already copied to the host with the counters (fqz_enc_launch)
     uint32_t hcap = 0, hcap_need = 0; // headers chunks the side buffers hold / the last batch needed
+    size_t hcap_need_bytes = 0;        // the size of the batch that reported hcap_need (a relaunch of it takes the exact need)
     double hcap_per_mb = 0;           // headers chunks per MiB of text of the last batch that overflowed the optimistic size
     DevBuf xmap;      // descriptors of every group (frame) for the content checksums | xsum[chunk_cap]
     DevBuf plans;     // BlockPlan[block_cap]

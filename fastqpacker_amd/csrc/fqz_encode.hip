@@ -798,9 +798,9 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
 }
 
 // ===========================================================================
-// K5/K6 entropy stage: one workgroup per 16 KiB chunk -> one zstd block
+// K5/K6 entropy stage: one workgroup per group of up to four 16 KiB chunks -> one zstd frame, one zstd block per chunk
 // (replaces zstd.Encoder.EncodeAll, compress.go:523-528; format: RFC 8878)
-// The construction is the deterministic "FQZ-H1" profile specified in DESIGN.md
+// The construction is the deterministic "FQZ-H2" profile specified in DESIGN.md §4
 // and restated on the CPU in oracle/fqz_entropy.c; outputs are byte-identical.
 // ===========================================================================
 // chunk id -> (block, stream, chunk index inside the stream).  Main chunks are numbered block by block in the
@@ -1361,7 +1361,8 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     // side buffers of the headers model: per headers chunk its sequences, literals, Sequences_Section (fqz_hdrlz.h).  Sized for
     // a quarter of the text being headers; a batch with more is relaunched with the exact need (fqz_enc_finish)
     uint32_t hcap = (uint32_t)(n / (4ull * FQZ_CHUNK)) + 2 * e.block_cap + 64;
-    if (e.hcap_need > hcap && e.n_bytes == n_bytes) hcap = e.hcap_need;
+    if (e.hcap_need > hcap && e.hcap_need_bytes == n_bytes) hcap = e.hcap_need; // (a relaunch of the batch that reported the need)
+    e.hcap_need = 0;
     if (e.hcap_per_mb > 0) { // a header-heavy input: the batches that follow one that overflowed are sized by its density
         const unsigned long long want = (unsigned long long)(e.hcap_per_mb * ((double)n / 1048576.0) * 1.05) + 2ull * e.block_cap + 64;
         if (want > hcap) hcap = want > main_cap ? (uint32_t)main_cap : (uint32_t)want;
@@ -1485,6 +1486,7 @@ int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uin
     }
     if (hi->status == FQZ_E_TOO_LARGE && hi->n_hchunks > e.hcap) { // more headers chunks than side buffers: relaunch with the exact need
         e.hcap_need = hi->n_hchunks + 16;
+        e.hcap_need_bytes = e.n_bytes;
         e.hcap_per_mb = (double)hi->n_hchunks / ((double)(e.n_bytes ? e.n_bytes : 1) / 1048576.0);
         return FQZ_E_TOO_LARGE;
     }

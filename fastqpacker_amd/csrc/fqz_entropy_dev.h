@@ -2,7 +2,7 @@
 // chunk of a pre-entropy stream into one zstd block.
 //
 // Replaces zstd.Encoder.EncodeAll (internal/compress/compress.go:523-528) with the deterministic
-// "FQZ-H1" construction of DESIGN.md §4; byte-identical to oracle/fqz_entropy.c.
+// "FQZ-H2" construction of DESIGN.md §4; byte-identical to oracle/fqz_entropy.c.
 //
 // The kernel is latency bound (serial chains in the table build), so its throughput is set by how many
 // workgroups a CU holds, i.e. by the LDS footprint.  The chunk therefore lives in REGISTERS: it is staged
@@ -64,7 +64,7 @@ __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_rea
 
 // ---------------------------------------------------------------------------------------------
 // FSE compression of the Huffman weights (only for alphabets with more than 128 weights).
-// FQZ-H1 does not fit a distribution to the weights of every chunk: it picks one of two fixed normalised
+// FQZ-H2 does not fit a distribution to the weights of every chunk: it picks one of two fixed normalised
 // distributions over the weight values 0..11 (table log 5) by the share of zero weights.  The NCount header and
 // the compression tables of both are compile-time constants; what is left per chunk is the encoding itself.
 // Mirrors oracle fse_compress_weights().

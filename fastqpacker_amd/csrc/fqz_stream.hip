@@ -377,7 +377,8 @@ static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *op
                         long r = io.read_full(bhb, hs);
                         if (r < 0) { P.fail((int)r); return; }
                         if (r == 0) { eof = true; break; }              // clean EOF at a block boundary (compress.go:614-617)
-                        if ((uint32_t)r < hs) { P.fail(FQZ_E_SHORT); return; }
+                        // (a version-3 file whose only content is the block table: 24 bytes, fewer than a block header)
+                        if ((uint32_t)r < hs && !(fh.version == FQZ_VERSION3 && r >= 8 && !memcmp(bhb, "\xFF\xFF\xFF\xFF" "FQZX", 8))) { P.fail(FQZ_E_SHORT); return; }
                     }
                     if (fh.version == FQZ_VERSION3 && !memcmp(bhb, "\xFF\xFF\xFF\xFF" "FQZX", 8)) { eof = true; break; } // the block table: the chain ends here (the rest is not read)
                     fqz_block_header bh;
@@ -674,7 +675,7 @@ extern "C" int fqz_compress_multi(const int *devices, int n_devices, const uint8
                 if (T == 0) a = 0;
                 else if (T > L[N]) a = n;
                 else { // one byte behind newline number T - 1 (0-based), which lies in the range e with L[e] <= T - 1 < L[e + 1]
-                    int e = d;
+                    int e = 0; // (from the first range: when L[d] is itself a block boundary, newline T - 1 lies in an EARLIER range)
                     while (e + 1 < N && L[e + 1] <= T - 1) e++;
                     unsigned long long j = T - 1 - L[e];
                     size_t tile = 0;
@@ -699,6 +700,9 @@ extern "C" int fqz_compress_multi(const int *devices, int n_devices, const uint8
         std::mutex mu;
         std::condition_variable cv;
         int file_enc = -1; // -1 not known yet, -2 the first shard failed
+        int lead = 0;      // the shard that holds block 0: it detects the encoding and writes the file header (shards in front of it are empty)
+        for (int d = 0; d < N; d++)
+            if (sh[d].a < sh[d].b) { lead = d; break; }
         std::vector<std::thread> th;
         for (int d = 0; d < N; d++)
             th.emplace_back([&, d] {
@@ -706,7 +710,7 @@ extern "C" int fqz_compress_multi(const int *devices, int n_devices, const uint8
                 (void)hipSetDevice(s.device);
                 ShardRole role;
                 if (want_table) role.table = &s.table;
-                if (d == 0) role.on_enc = [&](int e) { std::lock_guard<std::mutex> g(mu); file_enc = e; cv.notify_all(); };
+                if (d == lead) role.on_enc = [&](int e) { std::lock_guard<std::mutex> g(mu); file_enc = e; cv.notify_all(); };
                 else {
                     std::unique_lock<std::mutex> g(mu);
                     cv.wait(g, [&] { return file_enc != -1; });
@@ -724,7 +728,7 @@ extern "C" int fqz_compress_multi(const int *devices, int n_devices, const uint8
                 io.mem_in_n = s.b > ha ? s.b - ha : 0;
                 io.wr = grow_vec; io.wr_user = &s.out;
                 s.rc = compress_job(s.ctx, io, opts, &role);
-                if (d == 0) { std::lock_guard<std::mutex> g(mu); if (file_enc == -1) { file_enc = -2; cv.notify_all(); } }
+                if (d == lead) { std::lock_guard<std::mutex> g(mu); if (file_enc == -1) { file_enc = -2; cv.notify_all(); } }
             });
         for (auto &t : th) t.join();
         for (int d = 0; d < N && !rc; d++) rc = sh[d].rc; // the error of the earliest shard, like the ordered collector

@@ -35,6 +35,51 @@ def block_offsets_allgather(local_block_lens, max_blocks, device=None, group=Non
     return excl[start:start + n].tolist(), int(flat.sum().item()) + FILE_HEADER_SIZE, allsz
 
 
+class OffsetExchange:
+    """The same exchange with every buffer allocated once (the per-step form `bench.py` times): fill() copies this rank's block
+    sizes into a pinned staging row, run() moves it to the device, all-gathers and prefix-sums there, and returns device
+    tensors - nothing in a step allocates, builds Python lists or waits for the host."""
+
+    def __init__(self, max_blocks, world, device=None, group=None):
+        self.max_blocks, self.world, self.group = int(max_blocks), int(world), group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        on_gpu = device is not None and torch.device(device).type == "cuda"
+        self.host = torch.zeros(self.max_blocks, dtype=torch.int64)
+        if on_gpu:
+            self.host = self.host.pin_memory()
+        self.mine = torch.zeros(self.max_blocks, dtype=torch.int64, device=device)
+        self.all = torch.zeros(self.world * self.max_blocks, dtype=torch.int64, device=device)
+        self.n = 0
+
+    def fill(self, lens, at=0):
+        """lens: a sequence / numpy array of this rank's compressed block sizes, written at position `at` of the row."""
+        n = len(lens)
+        if at + n > self.max_blocks:
+            raise ValueError("more local blocks than max_blocks")
+        if n:
+            self.host[at:at + n] = torch.as_tensor(lens, dtype=torch.int64)
+        self.n = at + n
+        return self.n
+
+    def exchange(self):
+        """-> (offsets of the local blocks [n], file size [1]) as device tensors, all sizes [world, max_blocks]"""
+        self.host[self.n:] = 0
+        self.mine.copy_(self.host, non_blocking=True)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
+        else:
+            self.all.copy_(self.mine)
+        excl = torch.cumsum(self.all, 0) - self.all + FILE_HEADER_SIZE
+        start = self.rank * self.max_blocks
+        return excl[start:start + self.n], self.all.sum() + FILE_HEADER_SIZE, self.all.view(self.world, self.max_blocks)
+
+    def run(self, lens):
+        """fill + exchange, results on the host: (offsets list, total)"""
+        self.fill(lens)
+        offs, total, _ = self.exchange()
+        return offs.tolist(), int(total.item())
+
+
 def broadcast_encoding(encoding, src=0, device=None, group=None):
     """The quality encoding is a property of the FILE: the reference detects it once, on the first batch, and writes one
     FlagPhred64 for all blocks (compress.go:146-164).  Rank `src` (the rank that encodes block 0) detects it

@@ -17,9 +17,12 @@
  * independent.  The library never retains caller pointers past return.
  *
  * Wire format: container framing is the reference's (container.go:11-152,
- * SURVEY.md App. A).  Each of the six stream payloads is a standard zstd frame
- * (RFC 8878) made of Raw / RLE / Huffman-literal blocks, so the stock
- * `fqpack -d` (zstd.Decoder.DecodeAll, compress.go:785-814) reads our output.
+ * SURVEY.md App. A).  Each of the six stream payloads is a sequence of standard
+ * zstd frames (RFC 8878; the "FQZ-H2" profile of DESIGN.md section 4: a
+ * skippable index frame, then frames of Raw / RLE / Compressed blocks with
+ * Huffman-coded literals, sequences on the predefined FSE tables for the
+ * headers stream, and content checksums), so the stock `fqpack -d`
+ * (zstd.Decoder.DecodeAll, compress.go:785-814) reads our output.
  */
 #ifndef FQZ_H
 #define FQZ_H

@@ -159,3 +159,37 @@ def test_compress_multi_is_identical_to_one_device(fq):
     bad[at + 1] = ord("-")
     with pytest.raises(Exception):
         fq.compress.CompressMulti(bytes(bad), [0, 0])
+
+
+def test_compress_multi_range_boundary_on_a_block_boundary(fq):
+    """the byte range of device 1 starts exactly where block 1 starts (the lines in front of it are a non-zero multiple
+    of 400 000): the newline that ends block 0 lies in the EARLIER range.  Records of 2048 bytes: 100 000 of them fill
+    3125 counting tiles of 64 KiB exactly, so two devices cut the 200 000-record text at that very byte."""
+    rec = b"@hh\n" + b"ACGT" * 255 + b"\n+\n" + b"I" * 1020 + b"\n"
+    assert len(rec) == 2048
+    text = rec * 200_000
+    want = fq.compress.Compress(text)
+    assert fq.compress.CompressMulti(text, [0, 0]) == want
+    assert fq.compress.DecompressMulti(want, [0, 0]) == text
+
+
+def test_compress_multi_small_phred64_with_an_empty_first_shard(fq):
+    """a text smaller than two counting tiles leaves the first device's range empty; the shard that holds block 0 (the
+    second) must detect the encoding and write the header with FlagPhred64, as fqz_compress does."""
+    t64, _ = fq.compress.synth_fastq(400, min_len=40, max_len=60, phred=64)
+    t64 = t64.tobytes()
+    assert len(t64) < 2 * 65536
+    w64 = fq.compress.Compress(t64)
+    assert w64[9] & 2
+    assert fq.compress.CompressMulti(t64, [0, 0]) == w64
+    assert fq.compress.DecompressMulti(w64, [0, 0]) == t64
+
+
+def test_empty_v3_file_with_block_table_through_the_stream_reader(fq):
+    """empty input, container version 3 with a block table = file header + a 24-byte table and no block; the callback
+    reader must accept it like the memory path does."""
+    z = fq.compress.Compress(b"", fq.Options(0, 0, 3, 1))
+    assert len(z) == 10 + 24
+    out = io.BytesIO()
+    fq.compress.DecompressStream(io.BytesIO(z), out)
+    assert out.getvalue() == b"" and fq.compress.Decompress(z) == b""

@@ -92,3 +92,29 @@ def test_shard_records_covers_everything():
                     assert r0 == pos
                     pos += c
                     assert r0 % 100 == 0
+
+
+def test_bench_gpus2_starts_two_ranks():
+    """`bench.py --gpus 2` must start two ranks (launcher -> torchrun -> ranks) and rank 0 must print n_gpus: 2.  --dry-ranks
+    keeps the codec and the GPU out of it (gloo): what is proven is the launch path the driver's SCALE run depends on."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-ranks"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["dry_ranks"] is True and out["sharded_file_layout_ok"] is True
+
+
+def test_offset_exchange_matches_allgather_single_rank():
+    from fastqpacker_amd.sharding import OffsetExchange, block_offsets_allgather
+    lens = [5, 7, 11]
+    ex = OffsetExchange(8, 1)
+    offs, total = ex.run(lens)
+    o2, t2, _ = block_offsets_allgather(lens, 8)
+    assert offs == o2 == [10, 15, 22] and total == t2 == 33
