@@ -96,6 +96,14 @@ struct EncState {
     DevBuf csize;     // u32[chunk_cap+1] -> exclusive prefix
     DevBuf stamps;    // diagnostic s_memtime stamps (FQZ_DBG_STAMPS)
     bool streams_valid = false; // an encode has run: fqz_debug_get_streams can read its streams
+    // FQZ-S1 path (fqz_seg.h)
+    bool path_seg = false;      // the launch in flight took the segment path
+    bool groups_once = false;   // the next launch takes the group path whatever the default (fqz_enc_finish: blocks that do not qualify; test hooks)
+    bool no_mixed = false;      // inside enc_mixed
+    int qual_encoding = 0;
+    DevBuf segmeta;   // u32 bstart[block_cap + 2] | seg_base[block_cap + 2]
+    DevBuf seg;       // SegInfo[seg_cap + 2]
+    DevBuf hslots;    // headers blocks (FQZ_SLOT each) | SegHdrJob[hcap] | hcsize[hcap] | hord[hcap]
     PinnedBuf h_info; // EncInfo
     PinnedBuf h_plans;
 };

@@ -20,6 +20,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 // ===========================================================================
 // generic in-place exclusive scan of a u32 array (n may live on the device); data[n] receives the total.
@@ -1223,6 +1224,8 @@ __global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const Bloc
     if (t < n - tail0) dst[tail0 + t] = src[tail0 + t];
 }
 
+#include "fqz_seg.h"
+
 // ===========================================================================
 // host side
 // ===========================================================================
@@ -1260,12 +1263,159 @@ static inline uint32_t grid_for_waves(uint32_t n_items)
     return g ? g : 1;
 }
 
+static int enc_side_streams(EncState &e)
+{
+    if (e.side) return FQZ_OK;
+    // (the sequence sections are a chain of serial steps: with priority over the bulk entropy coders it is not the last to finish)
+    int prio_lo = 0, prio_hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIP_TRY(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e.ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&e.side2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e.ev_join2, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithPriority(&e.side3, hipStreamNonBlocking, prio_hi));
+    HIP_TRY(hipEventCreateWithFlags(&e.ev_join3, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e.ev_npos, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e.ev_gmap, hipEventDisableTiming));
+    return FQZ_OK;
+}
+
+static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags, uint8_t *d_out,
+                             size_t out_cap, hipStream_t st);
+
+// FQZ-S1 (fqz_seg.h): the default framing of container version 2.  Blocks that do not qualify are redone the FQZ-H2 way by
+// fqz_enc_finish (enc_mixed).
+static int enc_launch_seg(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags, uint8_t *d_out,
+                          size_t out_cap, hipStream_t st)
+{
+    EncState &e = ctx->enc;
+    if (n_bytes >= 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
+    if (((uintptr_t)d_text & 15) || ((uintptr_t)d_out & 15)) return FQZ_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t n = (uint32_t)n_bytes;
+    const uint32_t final_batch = (flags & FQZ_BATCH_FINAL) ? 1u : 0u;
+    e.n_tiles = (n + FQZ_TILE - 1) / FQZ_TILE;
+    e.rec_cap = n / 6 + 16;                                  // a record is at least six bytes
+    e.block_cap = e.rec_cap / rpb + 2;
+    const uint32_t seg_cap = n / SEG_TEXT + e.block_cap + 2; // ceil(bytes / SEG_TEXT) per block
+    const uint32_t chunk_cap = seg_cap * 12 + 16;            // csize / xsum entries: <= 4 + 5 blocks and a checksum id per segment
+    const uint32_t page_cap = seg_cap * ((SEG_ARENA + 5 * 64 + 4 * 64) / SEG_PAGE + 8) + 64;
+    const size_t sarena_cap = (size_t)seg_cap * (SEG_ARENA + 96) + 4096;
+    const uint32_t eh_cap = n / 6 + seg_cap + 64;
+    const uint32_t group_cap = seg_cap * FQZ_NS + 8;
+    e.chunk_cap = chunk_cap;
+    int rc;
+    if ((rc = e.info.ensure(sizeof(EncInfo)))) return rc;
+    if ((rc = e.tile_cnt.ensure(4ull * (e.n_tiles + 2)))) return rc;
+    if ((rc = e.plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
+    if ((rc = e.segmeta.ensure(8ull * (e.block_cap + 4)))) return rc;            // bstart | seg_base
+    if ((rc = e.seg.ensure(sizeof(SegInfo) * ((size_t)seg_cap + 2)))) return rc;
+    if ((rc = e.arena.ensure(sarena_cap + 64))) return rc;
+    if ((rc = e.slots.ensure((size_t)page_cap * SEG_PAGE + 64))) return rc;
+    if ((rc = e.csize.ensure(4ull * (2ull * chunk_cap + 16)))) return rc;         // csize | xsum
+    if ((rc = e.E.ensure(4ull * eh_cap))) return rc;                              // record offsets inside the headers parts
+    if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
+    if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
+    if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;                       // hmap
+    if ((rc = e.xmap.ensure(16ull * group_cap))) return rc;
+    // headers: a chunk per segment at least; sized for a quarter of the text being headers, relaunched with the exact need otherwise
+    uint32_t hcap = seg_cap + (uint32_t)(n / (4ull * FQZ_CHUNK)) + 64;
+    if (e.hcap_need > hcap && e.hcap_need_bytes == n_bytes) hcap = e.hcap_need;
+    e.hcap_need = 0;
+    e.hcap = hcap;
+    if ((rc = e.hside.ensure((size_t)hcap * (12ull * HDR_MAX_SEQ + FQZ_CHUNK + HDR_SEQ_CAP + sizeof(HdrSide) + 4 + 512) + 256))) return rc;
+    if ((rc = e.hslots.ensure((size_t)hcap * (FQZ_SLOT + sizeof(SegHdrJob) + 8) + 256))) return rc; // headers blocks | jobs | hcsize | hord
+    e.streams_valid = false;
+    e.d_text = d_text; e.n_bytes = n_bytes; e.rpb = rpb; e.flags = flags; e.d_out = d_out; e.out_cap = out_cap; e.stream = st;
+    e.qual_encoding = qual_encoding;
+
+    EncInfo *info = e.info.as<EncInfo>();
+    uint32_t *tile = e.tile_cnt.as<uint32_t>();
+    BlockPlan *plans = e.plans.as<BlockPlan>();
+    uint32_t *bstart = e.segmeta.as<uint32_t>(), *seg_base = bstart + e.block_cap + 2;
+    SegInfo *seg = e.seg.as<SegInfo>();
+    uint8_t *sarena = e.arena.as<uint8_t>(), *slots = e.slots.as<uint8_t>();
+    uint32_t *csize = e.csize.as<uint32_t>(), *xsum = csize + chunk_cap + 8;
+    uint32_t *ehbuf = e.E.as<uint32_t>();
+    uint4 *hmap = e.gmap.as<uint4>(), *xmap = e.xmap.as<uint4>();
+    uint2 *hseq = e.hside.as<uint2>();
+    uint32_t *hst = (uint32_t *)(hseq + (size_t)hcap * HDR_MAX_SEQ);
+    uint8_t *hlit = (uint8_t *)(hst + (size_t)hcap * HDR_MAX_SEQ), *hsec = hlit + (size_t)hcap * FQZ_CHUNK;
+    HdrSide *hside = (HdrSide *)(hsec + (size_t)hcap * HDR_SEQ_CAP);
+    uint32_t *hlist = (uint32_t *)(hside + hcap);
+    uint16_t *hhist = (uint16_t *)(hlist + hcap);
+    uint8_t *hslots = e.hslots.as<uint8_t>();
+    SegHdrJob *jobs = (SegHdrJob *)(hslots + (size_t)hcap * FQZ_SLOT);
+    uint32_t *hcsize = (uint32_t *)(jobs + hcap), *hord = hcsize + hcap;
+
+    const uint32_t zt_tiles = e.n_tiles / SCAN_TILE + 2;
+    if ((rc = e.zstate.ensure(8ull * (zt_tiles + 1)))) return rc;
+    unsigned long long *z_tiles = e.zstate.as<unsigned long long>();
+    hipLaunchKernelGGL(k_init, dim3((zt_tiles + 256) / 256 < 64 ? (zt_tiles + 256) / 256 : 64), dim3(256), 0, st, info, qual_encoding, z_tiles, zt_tiles + 1);
+    if (e.n_tiles) {
+        PROF(ctx, st, "k_count_nl", hipLaunchKernelGGL(k_count_nl, dim3(e.n_tiles), dim3(256), 0, st, d_text, n, tile));
+        if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, z_tiles))) return rc;
+    } else HIP_TRY(hipMemsetAsync(tile, 0, 8, st));
+    PROF(ctx, st, "k_seg_setup", hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(64), 0, st, info, tile, e.n_tiles, e.rec_cap, e.block_cap, rpb, final_batch));
+    PROF(ctx, st, "k_seg_blocks", hipLaunchKernelGGL(k_seg_blocks, dim3(e.block_cap + 2), dim3(64), 0, st, d_text, n, tile, e.n_tiles, info, bstart, rpb, final_batch));
+    PROF(ctx, st, "k_seg_plan", hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(256), 0, st, info, bstart, plans, seg_base, rpb, seg_cap));
+    PROF(ctx, st, "k_seg_table", hipLaunchKernelGGL(k_seg_table, dim3(seg_cap + 1), dim3(64), 0, st, d_text, n, tile, e.n_tiles, info, bstart, seg_base, seg, rpb));
+    if (qual_encoding == FQZ_DETECT_ENCODING) {
+        const uint32_t g0 = (uint32_t)((size_t)rpb * 6 > n ? n / SEG_TEXT + 2 : seg_cap); // (block 0's segments: the kernel knows how many)
+        PROF(ctx, st, "k_seg_detect", hipLaunchKernelGGL(k_seg_detect, dim3(g0 < seg_cap ? g0 : seg_cap), dim3(SEG_NT), 0, st, d_text, n, info, seg, plans, rpb));
+        hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
+    }
+    if ((rc = enc_side_streams(e))) return rc;
+    static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL"));
+    const hipStream_t sd = dbg_serial ? st : e.side, sd2 = dbg_serial ? st : e.side2, sd3 = dbg_serial ? st : e.side3;
+    PROF(ctx, st, "k_seg_encode", hipLaunchKernelGGL(k_seg_encode, dim3(seg_cap), dim3(SEG_NT), 0, st, d_text, n, info, seg, plans, rpb, sarena, sarena_cap, slots, page_cap, csize, chunk_cap,
+                                                     ehbuf, eh_cap, jobs, hord, hlist, hcap, hmap, xmap, group_cap));
+    HIP_TRY(hipEventRecord(e.ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0));
+    PROF(ctx, sd2, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd2, info, xmap, sarena, sarena, xsum));
+    HIP_TRY(hipEventRecord(e.ev_join2, e.side2));
+    PROF(ctx, st, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model_seg, dim3(hcap), dim3(256), 0, st, info, jobs, hcap, ehbuf, sarena, hseq, hlit, hside, hhist));
+    HIP_TRY(hipEventRecord(e.ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(e.side3, e.ev_fork, 0));
+    PROF(ctx, sd3, "k_hdr_seq1", hipLaunchKernelGGL(k_hdr_seq1, dim3((hcap + 15) / 16), dim3(64), 0, sd3, info, hcap, hseq, hst, hside));
+    PROF(ctx, sd3, "k_hdr_seq2", hipLaunchKernelGGL(k_hdr_seq2, dim3(hcap), dim3(64), 0, sd3, info, hcap, hseq, hst, hsec, hside));
+    HIP_TRY(hipEventRecord(e.ev_join3, e.side3));
+    const uint32_t hgroup_cap = seg_cap + 8 < group_cap ? seg_cap + 8 : group_cap;
+    PROF(ctx, st, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, st, info, hmap, sarena, hslots, hcsize, hord, hcap, hlit, hside, hhist));
+    HIP_TRY(hipStreamWaitEvent(st, e.ev_join3, 0));
+    PROF(ctx, st, "k_hdr_patch", hipLaunchKernelGGL(k_hdr_patch, dim3(hcap), dim3(64), 0, st, info, hlist, hcap, hside, hsec, hslots, hcsize));
+    HIP_TRY(hipStreamWaitEvent(st, e.ev_join2, 0));
+    PROF(ctx, st, "k_seg_sizes", hipLaunchKernelGGL(k_seg_sizes, dim3(e.block_cap), dim3(256), 0, st, info, plans, seg, csize, hcsize));
+    PROF(ctx, st, "k_seg_layout", hipLaunchKernelGGL(k_seg_layout, dim3(1), dim3(256), 0, st, info, plans, d_out, out_cap));
+    PROF(ctx, st, "k_seg_compact", hipLaunchKernelGGL(k_seg_compact, dim3(seg_cap), dim3(256), 0, st, info, plans, seg, slots, csize, hslots, hcsize, xsum, d_out));
+    (void)sd;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
+    e.plans_pre = e.block_cap < 256 ? e.block_cap : 256;
+    HIP_TRY(hipMemcpyAsync(e.h_plans.p, plans, sizeof(BlockPlan) * (size_t)e.plans_pre, hipMemcpyDeviceToHost, st));
+    e.in_flight = true;
+    return FQZ_OK;
+}
+
 int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags, uint8_t *d_out,
                    size_t out_cap, hipStream_t st)
 {
     EncState &e = ctx->enc;
     if (e.in_flight) return FQZ_E_ARG;
     if (!rpb) rpb = FQZ_DEFAULT_BLOCK_SIZE;
+    // FQZ_ENC_LEGACY=1: the FQZ-H2 group framing for every block (oracle: fqzo_options.framing = 1); container version 3 has no segment form
+    static const bool legacy = getenv("FQZ_ENC_LEGACY") && atoi(getenv("FQZ_ENC_LEGACY"));
+    e.path_seg = !legacy && !(flags & FQZ_BATCH_V3) && !e.groups_once;
+    e.groups_once = false;
+    if (e.path_seg) return enc_launch_seg(ctx, d_text, n_bytes, rpb, qual_encoding, flags, d_out, out_cap, st);
+    return enc_launch_groups(ctx, d_text, n_bytes, rpb, qual_encoding, flags, d_out, out_cap, st);
+}
+
+static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags, uint8_t *d_out,
+                             size_t out_cap, hipStream_t st)
+{
+    EncState &e = ctx->enc;
     if (n_bytes >= 0x7FFFFFFFull) return FQZ_E_TOO_LARGE;
     if (((uintptr_t)d_text & 15) || ((uintptr_t)d_out & 15)) return FQZ_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1376,20 +1526,7 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     HdrSide *hside = (HdrSide *)(hsec + (size_t)hcap * HDR_SEQ_CAP);
     uint32_t *hlist = (uint32_t *)(hside + hcap);
     uint16_t *hhist = (uint16_t *)(hlist + hcap);
-    if (!e.side) {
-        // (the sequence sections are a chain of serial steps: with priority over the bulk entropy coders it is not the last to finish)
-        int prio_lo = 0, prio_hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIP_TRY(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&e.ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&e.side2, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&e.ev_join2, hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithPriority(&e.side3, hipStreamNonBlocking, prio_hi));
-        HIP_TRY(hipEventCreateWithFlags(&e.ev_join3, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e.ev_npos, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e.ev_gmap, hipEventDisableTiming));
-    }
+    if ((rc = enc_side_streams(e))) return rc;
     static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: everything on one stream (standalone kernel times)
     static const int dbg_rans = getenv("FQZ_DBG_RANS") ? atoi(getenv("FQZ_DBG_RANS")) : 0;          // timing experiments on k_rans (garbage out)
     // side: the entropy stage over the headers' literals; side2: the rANS coder (version 3) and the content checksums; side3: the
@@ -1459,6 +1596,72 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     return FQZ_OK;
 }
 
+// A batch of the FQZ-S1 path in which some block does not qualify for the segment framing (a read too long for the segment
+// workgroup's LDS, records too short to count): the framing is decided block by block (oracle: encode_block_segments), so
+// the batch is encoded again as runs of blocks - a run of qualifying blocks through the segment path, a run of others
+// through the group path - each from an aligned copy of its text, and the pieces are put together in d_out.  Rare; synchronous.
+static int enc_mixed(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uint64_t *block_len, size_t max_blocks)
+{
+    EncState &e = ctx->enc;
+    const EncInfo first = *e.h_info.as<EncInfo>();
+    const uint32_t nb = first.n_blocks, rpb = e.rpb;
+    const uint8_t *d_text = e.d_text;
+    uint8_t *d_out = e.d_out;
+    const size_t out_cap = e.out_cap;
+    const uint32_t flags = e.flags;
+    const size_t n_bytes0 = e.n_bytes;
+    hipStream_t st = e.stream;
+    std::vector<uint32_t> bstart((size_t)nb + 1);
+    std::vector<BlockPlan> plans(nb);
+    HIP_TRY(hipMemcpy(bstart.data(), e.segmeta.p, 4ull * (nb + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(plans.data(), e.plans.p, sizeof(BlockPlan) * (size_t)nb, hipMemcpyDeviceToHost));
+    const int enc = first.qual_off == 64 ? FQZ_ENCODING_PHRED64 : FQZ_ENCODING_PHRED33;
+    DevBuf text, part; // (released at the end: this path is not worth a place in the context)
+    fqz_batch_result total;
+    memset(&total, 0, sizeof total);
+    total.n_records = first.n_rec; total.n_blocks = nb; total.consumed = first.consumed; total.qual_encoding = enc;
+    size_t pos = 0;
+    int rc = FQZ_OK;
+    for (uint32_t b0 = 0; b0 < nb && !rc;) {
+        uint32_t b1 = b0 + 1;
+        while (b1 < nb && (plans[b1].fallback != 0) == (plans[b0].fallback != 0)) b1++;
+        const size_t len = bstart[b1] - bstart[b0];
+        if ((rc = text.ensure(len + 64)) || (rc = part.ensure(fqz_encode_bound_blocks(len, rpb) + 64))) break;
+        if (hipMemcpyAsync(text.p, d_text + bstart[b0], len, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = FQZ_E_HIP; break; }
+        std::vector<uint64_t> off(b1 - b0), blen(b1 - b0);
+        fqz_batch_result r;
+        memset(&r, 0, sizeof r);
+        for (int attempt = 0;; attempt++) {
+            e.groups_once = plans[b0].fallback != 0;
+            e.no_mixed = true; // (a run is uniform by construction)
+            rc = fqz_enc_launch(ctx, text.as<uint8_t>(), len, rpb, enc, (flags & ~FQZ_BATCH_FINAL) | FQZ_BATCH_FINAL, part.as<uint8_t>(), part.cap, st);
+            if (!rc) rc = fqz_enc_finish(ctx, &r, off.data(), blen.data(), off.size());
+            e.no_mixed = false;
+            if (rc == FQZ_E_TOO_LARGE && attempt < 3) continue;
+            break;
+        }
+        if (rc) { if (r.status) { total.status = r.status; total.error_record = r.error_record + b0 * rpb; } break; }
+        if (r.n_blocks != b1 - b0 || pos + r.out_len > out_cap) { rc = r.n_blocks != b1 - b0 ? FQZ_E_HIP : FQZ_E_DST_SMALL; break; }
+        if (hipMemcpyAsync(d_out + pos, part.p, r.out_len, hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = FQZ_E_HIP; break; }
+        for (uint32_t b = b0; b < b1; b++) {
+            if (block_off && b < max_blocks) block_off[b] = pos + off[b - b0];
+            if (block_len && b < max_blocks) block_len[b] = blen[b - b0];
+        }
+        for (int s = 0; s < FQZ_NS; s++) { total.stream_raw[s] += r.stream_raw[s]; total.stream_comp[s] += r.stream_comp[s]; }
+        total.n_chunks += r.n_chunks;
+        pos += r.out_len;
+        b0 = b1;
+    }
+    text.release(); part.release();
+    e.d_text = d_text; e.d_out = d_out; e.out_cap = out_cap; e.flags = flags; e.n_bytes = n_bytes0; // (what fqz_debug_get_streams looks at)
+    e.streams_valid = false;
+    if (!rc && (block_off || block_len) && nb > max_blocks) rc = FQZ_E_DST_SMALL;
+    total.out_len = rc ? 0 : pos;
+    if (rc && !total.status) total.status = rc;
+    if (res) *res = total;
+    return rc;
+}
+
 int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uint64_t *block_len, size_t max_blocks)
 {
     EncState &e = ctx->enc;
@@ -1466,6 +1669,10 @@ int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uin
     e.in_flight = false;
     HIP_TRY(hipStreamSynchronize(e.stream));
     const EncInfo *hi = e.h_info.as<EncInfo>();
+    if (e.path_seg && !hi->status && hi->seg_fallback) {
+        if (e.no_mixed) return FQZ_E_HIP; // (cannot happen: this run qualified a moment ago)
+        return enc_mixed(ctx, res, block_off, block_len, max_blocks);
+    }
     if (res) {
         memset(res, 0, sizeof *res);
         res->n_records = hi->n_rec;
@@ -1515,7 +1722,21 @@ int fqz_enc_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_
 {
     EncState &e = ctx->enc;
     const EncInfo *hi = e.h_info.as<EncInfo>();
-    if (!hi || e.in_flight || block >= hi->n_blocks || !e.streams_valid) return FQZ_E_ARG;
+    if (!hi || e.in_flight) return FQZ_E_ARG;
+    if (!e.streams_valid && e.d_text) {
+        // the last encode took the segment path, which never holds a block's streams in one piece: the group path's front end over
+        // the same text (still in place: this is a test hook, called right behind the encode) rebuilds them
+        DevBuf scratch;
+        int rc = scratch.ensure(e.out_cap ? e.out_cap : 64);
+        if (rc) return rc;
+        e.groups_once = true;
+        rc = fqz_enc_launch(ctx, e.d_text, e.n_bytes, e.rpb, hi->qual_off == 64 ? FQZ_ENCODING_PHRED64 : FQZ_ENCODING_PHRED33, e.flags, scratch.as<uint8_t>(), scratch.cap, e.stream);
+        if (!rc) rc = fqz_enc_finish(ctx, nullptr, nullptr, nullptr, 0);
+        scratch.release();
+        if (rc) return rc;
+        hi = e.h_info.as<EncInfo>();
+    }
+    if (block >= hi->n_blocks || !e.streams_valid) return FQZ_E_ARG;
     BlockPlan p;
     HIP_TRY(hipMemcpy(&p, e.plans.as<BlockPlan>() + block, sizeof p, hipMemcpyDeviceToHost));
     for (int s = 0; s < FQZ_NS; s++) {

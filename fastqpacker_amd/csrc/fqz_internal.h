@@ -36,6 +36,11 @@ struct EncInfo {
     uint32_t n_hchunks;     // chunks of the headers streams (modelled before the entropy stage, fqz_hdrlz.h)
     uint32_t n_hgroups;     // their groups
     uint32_t n_rgroups;     // groups of the quality streams when they are coded with rANS (container version 3, fqz_rans.h)
+    uint32_t n_segs;        // FQZ-S1 path (fqz_seg.h): segments of the batch
+    uint32_t seg_fallback;  // some block does not qualify for the segment framing: the host encodes the batch's blocks the FQZ-H2 way where flagged
+    uint32_t eh_used;       // entries of the headers record-offset table in use
+    uint32_t pages_used;    // SEG_PAGE units of the slot pool handed out
+    unsigned long long sarena_used; // bytes of the stream arena handed out
     unsigned long long error_key; // (record << 8 | check order << 4 | code index), min wins
     unsigned long long out_len;
     unsigned long long stream_raw[FQZ_NS];
@@ -52,6 +57,8 @@ struct BlockPlan {
     uint32_t frame_len[FQZ_NS];
     uint32_t out_off, out_len;   // block header + payloads in d_out
     uint32_t orig_seq;           // sum of read lengths
+    uint32_t seg_base, n_seg;    // FQZ-S1: the block's segments
+    uint32_t fallback;           // FQZ-S1: a segment of the block does not qualify
 };
 
 // Decode side -------------------------------------------------------------

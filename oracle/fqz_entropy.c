@@ -905,6 +905,93 @@ size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, in
     return (size_t)(op - dst);
 }
 
+/* ===================================================================== */
+/* FQZ-S1: SEGMENT FRAMING of a block's payloads (container version 2)    */
+/* ===================================================================== */
+/* A block's text is cut into segments of FQZO_SEG_TEXT bytes, counted from the first byte of the block's first record; a
+ * record belongs to the segment its first byte ('@') lies in.  Every segment contributes ONE zstd frame to each of the six
+ * payloads - the part of that stream its records produce - so that one GPU workgroup turns a segment's text into its six
+ * frames without the pre-entropy streams ever leaving the chip.  A payload is
+ *   [index]  a zstd skippable frame: magic 0x184D2A50, size, 'FQZI', version 2, stream id, u16 flags (0), pre-entropy bytes of the
+ *            whole payload u32, number of segments u32, then per segment { u24 bytes of its frame (0: none), u24 pre-entropy bytes,
+ *            u16 records }: a decoder places every frame, every record range and every output range with three scans
+ *   [frames] per segment with content: magic, FHD 0x24 / 0x64 (Single_Segment, Content_Checksum, 1- or 2-byte content size), one
+ *            zstd block per 16 KiB of content with ONE Huffman table for the frame (FQZ-H2 rules: encode_group_chunks), checksum.
+ * Stock decoders read it as what it is: a skippable frame and a run of ordinary frames (DecodeAll semantics, compress.go:785-814).
+ * Per stream: packed bases Raw; headers modelled per 16 KiB chunk against the previous record (hdr_chunk_model); a chunk of the
+ * lengths stream whose u32 values are all equal is the first value as literals + ONE sequence (literal length 4, match length
+ * mk - 4, offset 4); everything else Huffman / RLE / Raw by the FQZ-H2 tests.
+ * A block qualifies only if every segment holds at most FQZO_SEG_RMAX records and its six stream parts, each rounded up to 16
+ * bytes, fit FQZO_SEG_ARENA bytes (what the workgroup keeps in LDS); any other block is written with the FQZ-H2 framing above. */
+size_t fqzo_seg_index_len(uint32_t n_seg) { return 24 + 8 * (size_t)n_seg; }
+
+void fqzo_seg_index_write(uint8_t *idx, int stream, uint32_t raw_total, uint32_t n_seg)
+{
+    put32le(idx, 0x184D2A50u);
+    put32le(idx + 4, (uint32_t)(fqzo_seg_index_len(n_seg) - 8));
+    idx[8] = 'F'; idx[9] = 'Q'; idx[10] = 'Z'; idx[11] = 'I';
+    idx[12] = 2; idx[13] = (uint8_t)stream; idx[14] = 0; idx[15] = 0;
+    put32le(idx + 16, raw_total);
+    put32le(idx + 20, n_seg);
+}
+
+void fqzo_seg_index_entry(uint8_t *idx, uint32_t seg, uint32_t comp, uint32_t raw, uint32_t nrec)
+{
+    uint8_t *e = idx + 24 + 8 * (size_t)seg;
+    e[0] = (uint8_t)comp; e[1] = (uint8_t)(comp >> 8); e[2] = (uint8_t)(comp >> 16);
+    e[3] = (uint8_t)raw; e[4] = (uint8_t)(raw >> 8); e[5] = (uint8_t)(raw >> 16);
+    e[6] = (uint8_t)nrec; e[7] = (uint8_t)(nrec >> 8);
+}
+
+/* the frame of one segment's part [src, src + n) of stream `stream`; n <= FQZO_GROUP * FQZO_CHUNK.  Returns its size (0 for n == 0) */
+size_t fqzo_seg_frame(const uint8_t *src, size_t n, int stream, uint8_t *dst)
+{
+    if (!n) return 0;
+    uint8_t *op = dst;
+    op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
+    if (n < 256) { op[4] = 0x24; op[5] = (uint8_t)n; op += 6; }
+    else { op[4] = 0x64; op[5] = (uint8_t)(n - 256); op[6] = (uint8_t)((n - 256) >> 8); op += 7; }
+    gchunk ch[FQZO_GROUP];
+    int nch = 0;
+    uint32_t *rs = NULL, nr = 0;
+    hseq *sqbuf = NULL;
+    uint8_t *litbuf = NULL;
+    if (stream == 2) { /* headers: record starts from the length prefixes (the part is a clean chain of whole records) */
+        rs = (uint32_t *)malloc(sizeof(uint32_t) * (n / 2 + 2));
+        size_t pos = 0;
+        while (pos + 2 <= n) { rs[nr++] = (uint32_t)pos; pos += 2 + (size_t)(src[pos] | (src[pos + 1] << 8)); }
+        if (pos != n) { free(rs); rs = NULL; nr = 0; } else rs[nr] = (uint32_t)n;
+        if (rs) { sqbuf = (hseq *)malloc(sizeof(hseq) * FQZO_GROUP * HDR_MAX_SEQ); litbuf = (uint8_t *)malloc((size_t)FQZO_GROUP * FQZO_CHUNK); }
+    }
+    hseq lseq[FQZO_GROUP];
+    for (size_t co = 0; co < n; co += FQZO_CHUNK, nch++) {
+        const uint32_t mk = (uint32_t)(n - co < FQZO_CHUNK ? n - co : FQZO_CHUNK);
+        ch[nch].raw = ch[nch].lit = src + co; ch[nch].mk = ch[nch].n_lit = mk; ch[nch].sq = NULL; ch[nch].nseq = 0;
+        if (rs) {
+            uint32_t nl = 0;
+            ch[nch].sq = sqbuf + (size_t)nch * HDR_MAX_SEQ;
+            ch[nch].lit = litbuf + co;
+            ch[nch].nseq = hdr_chunk_model(src, rs, nr, (uint32_t)co, mk, sqbuf + (size_t)nch * HDR_MAX_SEQ, litbuf + co, &nl);
+            ch[nch].n_lit = nl;
+        } else if (stream == 5 && mk >= 20 && (mk & 3) == 0) { /* lengths: all u32 of the chunk equal -> 4 literals + one match at offset 4
+                                                                 * (from 20 bytes on: below, the block would be judged worse than Raw) */
+            int same = 1;
+            for (uint32_t i = 4; i < mk && same; i++) same = src[co + i] == src[co + i - 4];
+            if (same) {
+                lseq[nch].ll = 4; lseq[nch].ml = mk - 4; lseq[nch].off = 4;
+                ch[nch].sq = &lseq[nch]; ch[nch].nseq = 1; ch[nch].n_lit = 4;
+            }
+        }
+    }
+    op += encode_group_chunks(ch, nch, stream == 0, op);
+    put32le(op, (uint32_t)fqzo_xxh64(src, n, 0));
+    op += 4;
+    free(rs); free(sqbuf); free(litbuf);
+    return (size_t)(op - dst);
+}
+
+size_t fqzo_seg_frame_bound(size_t n) { return n ? n + 7 + 4 + 3 * ((n + FQZO_CHUNK - 1) / FQZO_CHUNK) + 16 : 0; }
+
 /* a stream of no particular kind: Huffman-coded like the quality stream */
 size_t fqzo_entropy_encode(const uint8_t *src, size_t n, uint8_t *dst) { return fqzo_entropy_encode_stream(src, n, 1, dst); }
 

@@ -487,10 +487,80 @@ typedef struct {
     const fqzo_record *recs;
     size_t n_rec;
     int enc, entropy;
+    int framing;    /* fqzo_options.framing */
+    size_t text_end; /* first byte behind the block's last record */
     uint8_t *out; /* malloc'd block bytes */
     size_t out_len;
     int err;
 } enc_job;
+
+/* FQZ-S1 (fqz_entropy.c): the block as segments, if it qualifies.  Returns 1 and the block in j->out, 0 if the block does not
+ * qualify (the caller writes it with the FQZ-H2 framing), or a negative error.  `whole` = the streams of the whole block. */
+static int encode_block_segments(enc_job *j, const fqzo_streams *whole)
+{
+    const size_t B0 = j->recs[0].hdr_off - 1;
+    const uint32_t n_seg = (uint32_t)((j->text_end - B0 + FQZO_SEG_TEXT - 1) / FQZO_SEG_TEXT);
+    uint32_t *first = (uint32_t *)calloc((size_t)n_seg + 1, sizeof(uint32_t)); /* first record of every segment */
+    if (!first) return FQZO_E_NOMEM;
+    {
+        uint32_t seg = 0;
+        for (size_t r = 0; r < j->n_rec; r++) {
+            const uint32_t sr = (uint32_t)((j->recs[r].hdr_off - 1 - B0) / FQZO_SEG_TEXT);
+            while (seg < sr) first[++seg] = (uint32_t)r;
+        }
+        while (seg < n_seg) first[++seg] = (uint32_t)j->n_rec;
+    }
+    fqzo_streams *ss = (fqzo_streams *)calloc(n_seg ? n_seg : 1, sizeof(fqzo_streams));
+    if (!ss) { free(first); return FQZO_E_NOMEM; }
+    int ok = 1, err = 0;
+    for (uint32_t s = 0; s < n_seg && ok && !err; s++) {
+        const uint32_t cnt = first[s + 1] - first[s];
+        if (cnt > FQZO_SEG_RMAX) { ok = 0; break; }
+        if (!cnt) continue;
+        err = fqzo_split_block(j->text, j->recs + first[s], cnt, j->enc, &ss[s]);
+        if (err) break;
+        size_t need = 0;
+        for (int k = 0; k < FQZO_NSTREAMS; k++) need += (ss[s].len[k] + 15) & ~(size_t)15;
+        if (need > FQZO_SEG_ARENA) ok = 0;
+    }
+    uint8_t *out = NULL;
+    size_t w = 36;
+    if (ok && !err) {
+        size_t cap = 36;
+        for (int k = 0; k < FQZO_NSTREAMS; k++) {
+            cap += fqzo_seg_index_len(n_seg);
+            for (uint32_t s = 0; s < n_seg; s++) cap += fqzo_seg_frame_bound(ss[s].len[k]);
+        }
+        out = (uint8_t *)malloc(cap);
+        if (!out) err = FQZO_E_NOMEM;
+    }
+    if (ok && !err) {
+        uint32_t comp[FQZO_NSTREAMS];
+        for (int k = 0; k < FQZO_NSTREAMS; k++) { /* compress.go:523-528: order seq, qual, headers, plus, nPos, lengths */
+            comp[k] = 0;
+            if (!whole->len[k]) continue; /* an empty stream is an empty payload (EncodeAll without zero frames) */
+            uint8_t *idx = out + w;
+            fqzo_seg_index_write(idx, k, (uint32_t)whole->len[k], n_seg);
+            size_t p = w + fqzo_seg_index_len(n_seg);
+            for (uint32_t s = 0; s < n_seg; s++) {
+                const size_t fl = fqzo_seg_frame(ss[s].data[k], ss[s].len[k], k, out + p);
+                fqzo_seg_index_entry(idx, s, (uint32_t)fl, (uint32_t)ss[s].len[k], first[s + 1] - first[s]);
+                p += fl;
+            }
+            comp[k] = (uint32_t)(p - w);
+            w = p;
+        }
+        fqzo_block_header bh = { (uint32_t)j->n_rec, comp[0], comp[1], comp[2], comp[3], comp[4], comp[5],
+                                 whole->original_seq_size, whole->original_qual_size };
+        fqzo_write_block_header(&bh, 2, out);
+        j->out = out;
+        j->out_len = w;
+    }
+    for (uint32_t s = 0; s < n_seg; s++) fqzo_streams_free(&ss[s]);
+    free(ss); free(first);
+    if (err) { free(out); return err; }
+    return ok ? 1 : 0;
+}
 
 /* compress.go:471-555 compressBlockWithBuffers */
 static void encode_block_job(enc_job *j)
@@ -499,6 +569,10 @@ static void encode_block_job(enc_job *j)
     j->out = NULL; j->out_len = 0;
     j->err = fqzo_split_block(j->text, j->recs, j->n_rec, j->enc, &s);
     if (j->err) return;
+    if (j->entropy == 0 && j->framing == 0) {
+        const int r = encode_block_segments(j, &s);
+        if (r) { fqzo_streams_free(&s); if (r < 0) j->err = r; return; }
+    }
     size_t cap = 36;
     for (int k = 0; k < FQZO_NSTREAMS; k++)
         cap += j->entropy == 1 ? zs.bound(s.len[k]) : fqzo_entropy_bound(s.len[k]);
@@ -552,7 +626,7 @@ static int resolve_workers(int w)
 
 long fqzo_compress(const uint8_t *fastq, size_t n, uint8_t *out, size_t cap, const fqzo_options *opt)
 {
-    fqzo_options o = {0, 0, 0, 0, 0, 0};
+    fqzo_options o = {0, 0, 0, 0, 0, 0, 0};
     if (opt) o = *opt;
     if (o.block_index && o.entropy != 2) return FQZO_E_FILE_VERSION;
     if (!o.block_size) o.block_size = 100000;       /* compress.go:126-131 */
@@ -617,6 +691,14 @@ long fqzo_compress(const uint8_t *fastq, size_t n, uint8_t *out, size_t cap, con
         jobs[b].n_rec = (b + 1 == n_jobs) ? n_rec - b * o.batch_records : o.batch_records;
         jobs[b].enc = enc;
         jobs[b].entropy = o.entropy;
+        jobs[b].framing = o.framing;
+        if (b + 1 < n_jobs) jobs[b].text_end = jobs[b].recs[jobs[b].n_rec].hdr_off - 1;
+        else { /* behind the newline of the last record's quality line (a '\r' in front of it was stripped by the parser) */
+            const fqzo_record *lr = &jobs[b].recs[jobs[b].n_rec - 1];
+            size_t e = (size_t)lr->qual_off + lr->qual_len;
+            if (e < n && fastq[e] == '\r') e++;
+            jobs[b].text_end = e + 1;
+        }
     }
     job_pool pool = { jobs, n_jobs, 0, PTHREAD_MUTEX_INITIALIZER };
     if ((size_t)workers > n_jobs) workers = (int)n_jobs;

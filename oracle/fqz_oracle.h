@@ -144,7 +144,7 @@ long fqzo_join_block(const uint8_t *const data[FQZO_NSTREAMS], const size_t len[
 long fqzo_join_block_size(const uint8_t *const data[FQZO_NSTREAMS], const size_t len[FQZO_NSTREAMS],
                           uint32_t num_records);
 
-/* ---- entropy stage ("FQZ-H1" profile: zstd frames, Huffman literals only) --
+/* ---- entropy stage ("FQZ-H2" profile: zstd frames) --
  * Replaces zstd.Encoder.EncodeAll (compress.go:523-528).  Deterministic:
  * the HIP encoder must produce identical bytes (spec in DESIGN.md §Entropy).
  */
@@ -157,6 +157,15 @@ size_t fqzo_entropy_encode(const uint8_t *src, size_t n, uint8_t *dst);
 size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint8_t *dst);
 /* version 3 (FQZ-R1): the quality stream (stream 1) is coded with interleaved rANS blocks; version 2 = the above */
 size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, int version, uint8_t *dst);
+/* FQZ-S1, the segment framing of container version 2 (fqz_entropy.c): limits a block must meet, and the pieces of a payload */
+#define FQZO_SEG_TEXT 65536u   /* text bytes per segment, from the first byte of the block's first record */
+#define FQZO_SEG_RMAX 384u     /* records per segment */
+#define FQZO_SEG_ARENA 51200u  /* bytes of the six stream parts of a segment, each rounded up to 16 */
+size_t fqzo_seg_index_len(uint32_t n_seg);
+void fqzo_seg_index_write(uint8_t *idx, int stream, uint32_t raw_total, uint32_t n_seg);
+void fqzo_seg_index_entry(uint8_t *idx, uint32_t seg, uint32_t comp, uint32_t raw, uint32_t nrec);
+size_t fqzo_seg_frame(const uint8_t *src, size_t n, int stream, uint8_t *dst);
+size_t fqzo_seg_frame_bound(size_t n);
 /* XXH64 (zstd content checksum = its low 32 bits, seed 0) */
 uint64_t fqzo_xxh64(const uint8_t *p, size_t len, uint64_t seed);
 /* Decoder for any zstd frame made only of Raw / RLE / Compressed blocks whose
@@ -191,6 +200,8 @@ typedef struct {
                              * file whose first batch another process saw (multi-GPU sharding: rank 0 detects and broadcasts) */
     int block_index;        /* entropy == 2 only: 1 = append the block table behind the last block (include/fqz.h: FQZ-R1's optional
                              * on-disk block index) */
+    int framing;            /* entropy == 0 only: 0 = FQZ-S1 segment framing for every block that qualifies (the default of the HIP
+                             * encoder), 1 = FQZ-H2 group framing always (FQZ_ENC_LEGACY=1 there) */
 } fqzo_options;
 
 size_t fqzo_compress_bound(size_t n_bytes);

@@ -39,7 +39,7 @@ class Streams(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("block_size", C.c_uint32), ("workers", C.c_int), ("batch_records", C.c_uint32), ("entropy", C.c_int),
-                ("force_encoding", C.c_int), ("block_index", C.c_int)]
+                ("force_encoding", C.c_int), ("block_index", C.c_int), ("framing", C.c_int)]
 
 
 def build():
@@ -275,14 +275,15 @@ def huf_code_lengths(counts):
     return mx, bytes(nb)
 
 
-def compress(fastq, block_size=0, workers=1, batch_records=0, entropy=0, force_encoding=0, block_index=0) -> bytes:
-    """compress.Compress on a memory buffer (bytes or numpy uint8 array)."""
+def compress(fastq, block_size=0, workers=1, batch_records=0, entropy=0, force_encoding=0, block_index=0, framing=0) -> bytes:
+    """compress.Compress on a memory buffer (bytes or numpy uint8 array).  framing: 0 = FQZ-S1 segment framing for blocks that
+    qualify (what the HIP encoder writes by default), 1 = FQZ-H2 group framing always (FQZ_ENC_LEGACY=1 there)."""
     a = np.frombuffer(fastq, dtype=np.uint8) if not isinstance(fastq, np.ndarray) else fastq
     cap = lib().fqzo_compress_bound(a.size)
     if batch_records:  # tiny blocks: 36-byte block headers and six frame headers per block dwarf the library's bound
         cap += (int(np.count_nonzero(a == 10)) // 4 // batch_records + 2) * 320
     out = np.empty(cap, dtype=np.uint8)
-    opt = Options(block_size, workers, batch_records, entropy, force_encoding, block_index)
+    opt = Options(block_size, workers, batch_records, entropy, force_encoding, block_index, framing)
     r = lib().fqzo_compress(a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, C.byref(opt))
     if r < 0:
         raise OracleError(r)
