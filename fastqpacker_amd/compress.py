@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import (lib, check, default_ctx, BatchResult, Options, DecompressOptions, FqzError, DEFAULT_BLOCK_SIZE,
-                   DETECT_ENCODING, BATCH_FINAL, BATCH_V3, SynthParams)
+                   DETECT_ENCODING, BATCH_FINAL, BATCH_V3, BATCH_SEG, SynthParams)
 
 DefaultBlockSize = DEFAULT_BLOCK_SIZE  # compress.go:71
 
@@ -178,14 +178,15 @@ def entropy_decode(frame: bytes, cap: int, ctx=None) -> bytes:
 
 
 def encode_batch_dev(d_fastq_ptr, n_bytes, d_out_ptr, out_cap, records_per_block=DEFAULT_BLOCK_SIZE,
-                     qual_encoding=DETECT_ENCODING, final=True, stream=None, ctx=None, max_blocks=0, container_version=2):
-    """Device-resident batch encode; pointers are raw device addresses (e.g. torch tensor.data_ptr())."""
+                     qual_encoding=DETECT_ENCODING, final=True, stream=None, ctx=None, max_blocks=0, container_version=2, segments=False):
+    """Device-resident batch encode; pointers are raw device addresses (e.g. torch tensor.data_ptr()).  segments: the experimental
+    FQZ-S1 framing (FQZ_BATCH_SEG)."""
     ctx = ctx or default_ctx()
     res = BatchResult()
     offs = (C.c_uint64 * max_blocks)() if max_blocks else None
     lens = (C.c_uint64 * max_blocks)() if max_blocks else None
     rc = lib().fqz_encode_batch_dev(ctx.handle, d_fastq_ptr, n_bytes, records_per_block, qual_encoding,
-                                    (BATCH_FINAL if final else 0) | (BATCH_V3 if container_version == 3 else 0),
+                                    (BATCH_FINAL if final else 0) | (BATCH_V3 if container_version == 3 else 0) | (BATCH_SEG if segments else 0),
                                     d_out_ptr, out_cap, C.byref(res), offs, lens, max_blocks, stream)
     if rc:
         raise FqzError(rc, "record %d" % res.error_record if res.status and -8 <= res.status <= -5 else "")

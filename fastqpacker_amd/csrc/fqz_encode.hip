@@ -997,7 +997,7 @@ __global__ __launch_bounds__(64) void k_xxh(const EncInfo *info, const uint4 *xm
     if (on) gd = xmap[g];
     const uint32_t s = gd.z >> 28;
     const unsigned long long h = xxh64_quad((s == S_NPOS ? npos_arena : arena) + gd.y, on ? gd.z & 0xFFFFFFu : 0u, lane);
-    if (on && (lane & 3) == 0) xsum[gd.x] = (uint32_t)h;
+    if (on && (lane & 3) == 0 && (gd.z & 0xFFFFFFu)) xsum[gd.x] = (uint32_t)h; // (the segment path lists empty frames too)
 }
 
 // N positions: u16 count + ascending u16 positions per record (compress.go:477-488, 507-512)
@@ -1241,7 +1241,7 @@ static unsigned long long *fqz_dbg_stamps(EncState &e)
     static int on = -1;
     if (on < 0) { const char *v = getenv("FQZ_DBG_STAMPS"); on = v ? atoi(v) : 0; }
     if (!on) return nullptr;
-    if (e.stamps.ensure((size_t)e.chunk_cap * 16 * 8)) return nullptr;
+    if (e.stamps.ensure((size_t)e.chunk_cap * 16 * 8)) return nullptr; // (segment path: chunk_cap = 12 entries a segment; it uses 2 x 16 words)
     (void)hipMemset(e.stamps.p, 0, (size_t)e.chunk_cap * 16 * 8);
     return e.stamps.as<unsigned long long>();
 }
@@ -1250,7 +1250,8 @@ int fqz_enc_get_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_chunks,
     EncState &e = ctx->enc;
     const EncInfo *hi = e.h_info.as<EncInfo>();
     if (!hi || !e.stamps.p) return FQZ_E_ARG;
-    size_t n = hi->n_chunks < max_chunks ? hi->n_chunks : max_chunks;
+    const size_t have = e.path_seg ? 2 * (size_t)((e.chunk_cap - 16) / SEG_IDS) : hi->n_chunks; // (segment path: 16 words a segment, then the quality coder's)
+    size_t n = have < max_chunks ? have : max_chunks;
     HIP_TRY(hipMemcpy(out, e.stamps.p, n * 16 * 8, hipMemcpyDeviceToHost));
     *n_chunks = n;
     return FQZ_OK;
@@ -1284,8 +1285,7 @@ static int enc_side_streams(EncState &e)
 static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags, uint8_t *d_out,
                              size_t out_cap, hipStream_t st);
 
-// FQZ-S1 (fqz_seg.h): the default framing of container version 2.  Blocks that do not qualify are redone the FQZ-H2 way by
-// fqz_enc_finish (enc_mixed).
+// FQZ-S1 (fqz_seg.h), on request (FQZ_BATCH_SEG).  Blocks that do not qualify are redone the FQZ-H2 way by fqz_enc_finish (enc_mixed).
 static int enc_launch_seg(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags, uint8_t *d_out,
                           size_t out_cap, hipStream_t st)
 {
@@ -1299,11 +1299,7 @@ static int enc_launch_seg(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, u
     e.rec_cap = n / 6 + 16;                                  // a record is at least six bytes
     e.block_cap = e.rec_cap / rpb + 2;
     const uint32_t seg_cap = n / SEG_TEXT + e.block_cap + 2; // ceil(bytes / SEG_TEXT) per block
-    const uint32_t chunk_cap = seg_cap * 12 + 16;            // csize / xsum entries: <= 4 + 5 blocks and a checksum id per segment
-    const uint32_t page_cap = seg_cap * ((SEG_ARENA + 5 * 64 + 4 * 64) / SEG_PAGE + 8) + 64;
-    const size_t sarena_cap = (size_t)seg_cap * (SEG_ARENA + 96) + 4096;
-    const uint32_t eh_cap = n / 6 + seg_cap + 64;
-    const uint32_t group_cap = seg_cap * FQZ_NS + 8;
+    const uint32_t chunk_cap = seg_cap * SEG_IDS + 16;       // csize / xsum entries
     e.chunk_cap = chunk_cap;
     int rc;
     if ((rc = e.info.ensure(sizeof(EncInfo)))) return rc;
@@ -1311,21 +1307,22 @@ static int enc_launch_seg(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, u
     if ((rc = e.plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
     if ((rc = e.segmeta.ensure(8ull * (e.block_cap + 4)))) return rc;            // bstart | seg_base
     if ((rc = e.seg.ensure(sizeof(SegInfo) * ((size_t)seg_cap + 2)))) return rc;
-    if ((rc = e.arena.ensure(sarena_cap + 64))) return rc;
-    if ((rc = e.slots.ensure((size_t)page_cap * SEG_PAGE + 64))) return rc;
+    if ((rc = e.arena.ensure((size_t)seg_cap * SEG_ASTRIDE + 64))) return rc;
+    if ((rc = e.slots.ensure((size_t)seg_cap * SEG_SLOT_PAGES * SEG_PAGE + 64))) return rc;
     if ((rc = e.csize.ensure(4ull * (2ull * chunk_cap + 16)))) return rc;         // csize | xsum
-    if ((rc = e.E.ensure(4ull * eh_cap))) return rc;                              // record offsets inside the headers parts
+    if ((rc = e.E.ensure(4ull * (size_t)seg_cap * (SEG_RMAX + 1) + 64))) return rc; // record offsets inside the headers parts
     if ((rc = e.h_info.ensure(sizeof(EncInfo)))) return rc;
     if ((rc = e.h_plans.ensure(sizeof(BlockPlan) * (size_t)e.block_cap))) return rc;
-    if ((rc = e.gmap.ensure(16ull * group_cap))) return rc;                       // hmap
-    if ((rc = e.xmap.ensure(16ull * group_cap))) return rc;
-    // headers: a chunk per segment at least; sized for a quarter of the text being headers, relaunched with the exact need otherwise
-    uint32_t hcap = seg_cap + (uint32_t)(n / (4ull * FQZ_CHUNK)) + 64;
+    if ((rc = e.gmap.ensure(16ull * (seg_cap + 8)))) return rc;                   // hmap
+    if ((rc = e.xmap.ensure(16ull * FQZ_NS * (seg_cap + 8)))) return rc;
+    // headers: a chunk ordinal per segment; parts longer than a chunk (rare) take theirs behind (a batch that needs more than this is
+    // relaunched with the exact need)
+    uint32_t hcap = seg_cap + seg_cap / 8 + 64;
     if (e.hcap_need > hcap && e.hcap_need_bytes == n_bytes) hcap = e.hcap_need;
     e.hcap_need = 0;
     e.hcap = hcap;
     if ((rc = e.hside.ensure((size_t)hcap * (12ull * HDR_MAX_SEQ + FQZ_CHUNK + HDR_SEQ_CAP + sizeof(HdrSide) + 4 + 512) + 256))) return rc;
-    if ((rc = e.hslots.ensure((size_t)hcap * (FQZ_SLOT + sizeof(SegHdrJob) + 8) + 256))) return rc; // headers blocks | jobs | hcsize | hord
+    if ((rc = e.hslots.ensure((size_t)hcap * sizeof(SegHdrJob) + 256))) return rc; // headers jobs
     e.streams_valid = false;
     e.d_text = d_text; e.n_bytes = n_bytes; e.rpb = rpb; e.flags = flags; e.d_out = d_out; e.out_cap = out_cap; e.stream = st;
     e.qual_encoding = qual_encoding;
@@ -1343,11 +1340,8 @@ static int enc_launch_seg(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, u
     uint32_t *hst = (uint32_t *)(hseq + (size_t)hcap * HDR_MAX_SEQ);
     uint8_t *hlit = (uint8_t *)(hst + (size_t)hcap * HDR_MAX_SEQ), *hsec = hlit + (size_t)hcap * FQZ_CHUNK;
     HdrSide *hside = (HdrSide *)(hsec + (size_t)hcap * HDR_SEQ_CAP);
-    uint32_t *hlist = (uint32_t *)(hside + hcap);
-    uint16_t *hhist = (uint16_t *)(hlist + hcap);
-    uint8_t *hslots = e.hslots.as<uint8_t>();
-    SegHdrJob *jobs = (SegHdrJob *)(hslots + (size_t)hcap * FQZ_SLOT);
-    uint32_t *hcsize = (uint32_t *)(jobs + hcap), *hord = hcsize + hcap;
+    uint16_t *hhist = (uint16_t *)((uint32_t *)(hside + hcap) + hcap);
+    SegHdrJob *jobs = e.hslots.as<SegHdrJob>();
 
     const uint32_t zt_tiles = e.n_tiles / SCAN_TILE + 2;
     if ((rc = e.zstate.ensure(8ull * (zt_tiles + 1)))) return rc;
@@ -1369,11 +1363,10 @@ static int enc_launch_seg(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, u
     if ((rc = enc_side_streams(e))) return rc;
     static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL"));
     const hipStream_t sd = dbg_serial ? st : e.side, sd2 = dbg_serial ? st : e.side2, sd3 = dbg_serial ? st : e.side3;
-    PROF(ctx, st, "k_seg_encode", hipLaunchKernelGGL(k_seg_encode, dim3(seg_cap), dim3(SEG_NT), 0, st, d_text, n, info, seg, plans, rpb, sarena, sarena_cap, slots, page_cap, csize, chunk_cap,
-                                                     ehbuf, eh_cap, jobs, hord, hlist, hcap, hmap, xmap, group_cap));
+    PROF(ctx, st, "k_seg_encode", hipLaunchKernelGGL(k_seg_encode, dim3(seg_cap), dim3(SEG_NT), 0, st, d_text, n, info, seg, plans, rpb, sarena, slots, csize, ehbuf, jobs, hcap, hmap, xmap, fqz_dbg_stamps(e)));
     HIP_TRY(hipEventRecord(e.ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(e.side2, e.ev_fork, 0));
-    PROF(ctx, sd2, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd2, info, xmap, sarena, sarena, xsum));
+    PROF(ctx, sd2, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((FQZ_NS * seg_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, sd2, info, xmap, sarena, sarena, xsum));
     HIP_TRY(hipEventRecord(e.ev_join2, e.side2));
     PROF(ctx, st, "k_hdr_model", hipLaunchKernelGGL(k_hdr_model_seg, dim3(hcap), dim3(256), 0, st, info, jobs, hcap, ehbuf, sarena, hseq, hlit, hside, hhist));
     HIP_TRY(hipEventRecord(e.ev_fork, st));
@@ -1381,14 +1374,13 @@ static int enc_launch_seg(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, u
     PROF(ctx, sd3, "k_hdr_seq1", hipLaunchKernelGGL(k_hdr_seq1, dim3((hcap + 15) / 16), dim3(64), 0, sd3, info, hcap, hseq, hst, hside));
     PROF(ctx, sd3, "k_hdr_seq2", hipLaunchKernelGGL(k_hdr_seq2, dim3(hcap), dim3(64), 0, sd3, info, hcap, hseq, hst, hsec, hside));
     HIP_TRY(hipEventRecord(e.ev_join3, e.side3));
-    const uint32_t hgroup_cap = seg_cap + 8 < group_cap ? seg_cap + 8 : group_cap;
-    PROF(ctx, st, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr, dim3(hgroup_cap), dim3(256), 0, st, info, hmap, sarena, hslots, hcsize, hord, hcap, hlit, hside, hhist));
+    PROF(ctx, st, "k_entropy_hdr", hipLaunchKernelGGL(k_entropy_hdr_seg, dim3(seg_cap), dim3(256), 0, st, info, hmap, seg, sarena, slots, csize, hcap, hlit, hside, hhist));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join3, 0));
-    PROF(ctx, st, "k_hdr_patch", hipLaunchKernelGGL(k_hdr_patch, dim3(hcap), dim3(64), 0, st, info, hlist, hcap, hside, hsec, hslots, hcsize));
+    PROF(ctx, st, "k_hdr_patch", hipLaunchKernelGGL(k_hdr_patch_seg, dim3(hcap), dim3(64), 0, st, info, jobs, hcap, hside, hsec, slots, csize));
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join2, 0));
-    PROF(ctx, st, "k_seg_sizes", hipLaunchKernelGGL(k_seg_sizes, dim3(e.block_cap), dim3(256), 0, st, info, plans, seg, csize, hcsize));
+    PROF(ctx, st, "k_seg_sizes", hipLaunchKernelGGL(k_seg_sizes, dim3(e.block_cap), dim3(256), 0, st, info, plans, seg, csize));
     PROF(ctx, st, "k_seg_layout", hipLaunchKernelGGL(k_seg_layout, dim3(1), dim3(256), 0, st, info, plans, d_out, out_cap));
-    PROF(ctx, st, "k_seg_compact", hipLaunchKernelGGL(k_seg_compact, dim3(seg_cap), dim3(256), 0, st, info, plans, seg, slots, csize, hslots, hcsize, xsum, d_out));
+    PROF(ctx, st, "k_seg_compact", hipLaunchKernelGGL(k_seg_compact, dim3(seg_cap), dim3(256), 0, st, info, plans, seg, slots, csize, xsum, d_out));
     (void)sd;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
@@ -1404,9 +1396,10 @@ int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t
     EncState &e = ctx->enc;
     if (e.in_flight) return FQZ_E_ARG;
     if (!rpb) rpb = FQZ_DEFAULT_BLOCK_SIZE;
-    // FQZ_ENC_LEGACY=1: the FQZ-H2 group framing for every block (oracle: fqzo_options.framing = 1); container version 3 has no segment form
-    static const bool legacy = getenv("FQZ_ENC_LEGACY") && atoi(getenv("FQZ_ENC_LEGACY"));
-    e.path_seg = !legacy && !(flags & FQZ_BATCH_V3) && !e.groups_once;
+    // FQZ-S1 (fqz_seg.h) is opt-in: FQZ_BATCH_SEG in `flags`, or FQZ_ENC_SEG=1 in the environment for every entry point (oracle:
+    // fqzo_options.framing = 1); container version 3 has no segment form
+    static const bool env_seg = getenv("FQZ_ENC_SEG") && atoi(getenv("FQZ_ENC_SEG"));
+    e.path_seg = (env_seg || (flags & FQZ_BATCH_SEG)) && !(flags & FQZ_BATCH_V3) && !e.groups_once;
     e.groups_once = false;
     if (e.path_seg) return enc_launch_seg(ctx, d_text, n_bytes, rpb, qual_encoding, flags, d_out, out_cap, st);
     return enc_launch_groups(ctx, d_text, n_bytes, rpb, qual_encoding, flags, d_out, out_cap, st);
@@ -1634,7 +1627,7 @@ static int enc_mixed(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, u
         for (int attempt = 0;; attempt++) {
             e.groups_once = plans[b0].fallback != 0;
             e.no_mixed = true; // (a run is uniform by construction)
-            rc = fqz_enc_launch(ctx, text.as<uint8_t>(), len, rpb, enc, (flags & ~FQZ_BATCH_FINAL) | FQZ_BATCH_FINAL, part.as<uint8_t>(), part.cap, st);
+            rc = fqz_enc_launch(ctx, text.as<uint8_t>(), len, rpb, enc, flags | FQZ_BATCH_FINAL | FQZ_BATCH_SEG, part.as<uint8_t>(), part.cap, st);
             if (!rc) rc = fqz_enc_finish(ctx, &r, off.data(), blen.data(), off.size());
             e.no_mixed = false;
             if (rc == FQZ_E_TOO_LARGE && attempt < 3) continue;

@@ -42,7 +42,7 @@ struct EntropyLds {
                                          // table build; then the zstd block
     uint32_t ctab[256];                  // byte histogram during the load, then code | nbits << 16
     uint32_t cc[128];                    // canonical-code scratch
-    uint32_t misc[32];
+    uint32_t misc[64];                   // (32..63: the two halves of a 512-thread segment workgroup, fqz_seg_entropy.h)
     uint8_t nbits[256];
     uint8_t w[256];
 #ifdef FQZ_LDS_PAD
@@ -147,6 +147,7 @@ __constant__ const FseFixed c_fse_fixed[2] = {
 // start states are then chained through the end-state maps, every weight position looks up the state it is
 // encoded from in the recorded trace, and the bit stream is assembled with a wave scan.
 // Returns the compressed size (valid in wave 0): 0 = nothing to code.
+#define FSE_WEIGHTS_BARRIERS 5 // workgroup barriers inside (n > 2): what threads beyond the first 256 of a larger workgroup must match
 __device__ __forceinline__ uint32_t fse_weights_wg(EntropyLds &S, HufScratch *sc, int n_in, unsigned long long *stamps = nullptr)
 {
 #define FSE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -360,9 +361,11 @@ struct HdrGroup {
 };
 #define HDR_SSZ_BOUND(n) (((n) < 128u ? 2u : 3u) + ((n) * 66u + 18u + 7u) / 8u)
 
+// xh (the segment path, fqz_seg.h): the byte histogram of every chunk of the group, [chunk][256] counts, made while the part was
+// written - phase 1 then has nothing to read
 template <bool HDR>
-__device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const uint32_t M, const uint32_t force_raw, uint8_t *slot0, uint32_t *csize0,
-                                     const int dbg_stop = 0, unsigned long long *stamps = nullptr, const HdrGroup *H = nullptr)
+__device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const uint32_t M, const uint32_t force_raw, uint8_t *slot0, uint32_t *csize0,
+                                     const int dbg_stop = 0, unsigned long long *stamps = nullptr, const HdrGroup *H = nullptr, const uint32_t *xh = nullptr)
 {
     const uint32_t last = 1;
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -384,8 +387,22 @@ __device__ void entropy_encode_group(EntropyLds &S, const uint8_t *src, const ui
         }
         S.ctab[t] = c;
     }
+    if (!HDR && xh) { // a chunk whose histogram has one bin with all its bytes is one repeated byte
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < nchunk; k++) {
+            const uint32_t mk = M - k * FQZ_CHUNK < FQZ_CHUNK ? M - k * FQZ_CHUNK : FQZ_CHUNK, h = xh[256 * k + t];
+            c += h;
+            const unsigned long long full = __ballot(h == mk);
+            __syncthreads();
+            if ((t & 63) == 0) S.misc[8 + (t >> 6)] = full ? 1u : 0u;
+            __syncthreads();
+            if (S.misc[8] | S.misc[9] | S.misc[10] | S.misc[11]) same_mask |= 1u << k;
+        }
+        S.ctab[t] = c;
+        __syncthreads();
+    }
 #pragma clang loop unroll(disable)
-    for (uint32_t k = 0; k < ((force_raw || HDR) ? 0u : nchunk); k++) {
+    for (uint32_t k = 0; k < ((force_raw || HDR || xh) ? 0u : nchunk); k++) {
         const uint32_t mk = M - k * FQZ_CHUNK < FQZ_CHUNK ? M - k * FQZ_CHUNK : FQZ_CHUNK;
         const uint8_t *csrc = HDR ? H->lit[k] : src + (size_t)k * FQZ_CHUNK;
         ChunkSyms C;

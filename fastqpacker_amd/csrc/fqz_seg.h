@@ -18,13 +18,18 @@
 //   k_hdr_model_seg ...      headers: model, sequence sections, literals (fqz_hdrlz.h), per segment
 //   k_seg_sizes, k_seg_layout, k_seg_compact   frame sizes -> payload and block offsets -> the blocks in their final place
 #pragma once
+#include "fqz_seg_entropy.h"
 
 #define SEG_TEXT 65536u     // == FQZO_SEG_TEXT
 #define SEG_RMAX 384u       // == FQZO_SEG_RMAX
 #define SEG_ARENA 51200u    // == FQZO_SEG_ARENA
 #define SEG_SPAN_MAX 131072u // text bytes of a segment's records beyond which it cannot qualify (its streams are at least ~0.6 of the text)
-#define SEG_NT 256u
-#define SEG_PAGE 1024u      // allocation unit of the slot pool
+#define SEG_NT 512u      // threads of a segment workgroup
+#define SEG_NW (SEG_NT / 64u)
+#define SEG_PAGE 1024u      // unit of the slot pool
+#define SEG_IDS 12u         // csize / xsum entries of a segment: at most 4 + 5 zstd blocks (51200 bytes in five parts), one id per frame
+#define SEG_SLOT_PAGES 60u  // slot pool pages of a segment: the sum of seg_pages over parts that fit SEG_ARENA
+#define SEG_ASTRIDE (SEG_ARENA + 96u) // stream arena bytes of a segment
 // slot pool pages of a part of M bytes: one chunk -> its worst-case block; several -> FQZ_SLOT apart, as the entropy coder writes them
 __host__ __device__ static inline uint32_t seg_pages(uint32_t M, int s)
 {
@@ -44,9 +49,13 @@ struct SegInfo {                 // one per segment (+ a closing entry)
     uint32_t a_off[FQZ_NS];      // the part in the stream arena (S_HDR also read by the headers model)
     uint32_t foff[FQZ_NS];       // the frame inside its payload, behind the index (k_seg_sizes)
     uint32_t flen[FQZ_NS];       // frame bytes
+    uint32_t hx;                 // headers chunks 1, 2, ... of the part (rare): their ordinals start here (chunk 0 has the segment's number)
+    uint32_t pad_;
 };
 
-struct SegHdrJob { uint32_t a_off, e_off, nrec, c0, mk, chunk, pad0, pad1; }; // one headers chunk of a segment for k_hdr_model_seg
+// one headers chunk of a segment for the headers kernels: where it lies in the stream arena, its records, its ordinal in the side
+// buffers, where its zstd block goes (byte offset in the slot pool) and which csize entry it has
+struct SegHdrJob { uint32_t a_off, e_off, nrec, c0, mk, chunk, slot_off, cs; };
 
 // ---------------------------------------------------------------------------------------------
 // line -> byte offset from the scanned newline counts (one wave; every lane calls and gets the result)
@@ -190,7 +199,9 @@ __global__ __launch_bounds__(256) void k_seg_plan(EncInfo *info, const uint32_t 
     if (t == 0) {
         seg_base[n_blocks] = carry;
         info->n_segs = carry;
-        if (carry > seg_cap) { info->status = FQZ_E_TOO_LARGE; info->n_segs = 0; info->n_blocks = 0; info->n_rec = 0; }
+        info->n_hchunks = carry;            // headers chunk ordinals: a segment's first chunk has its number; further ones are handed out behind
+        info->n_xgroups = FQZ_NS * carry;   // frames for the checksums: a list entry per segment and stream (empty ones are skipped)
+        if (carry > seg_cap) { info->status = FQZ_E_TOO_LARGE; info->n_segs = 0; info->n_blocks = 0; info->n_rec = 0; info->n_hchunks = 0; info->n_xgroups = 0; }
     }
 }
 
@@ -238,7 +249,8 @@ struct SegLds {
         EntropyLds ent;
         __device__ U() {}
     } u;
-    uint32_t sh[16];
+    uint32_t qhist[4][256];  // byte histogram of every 16 KiB chunk of the quality part, counted while it is written
+    uint32_t sh[4 * SEG_NW];
     uint32_t reg[FQZ_NS + 1]; // region starts inside the arena
     uint32_t raw[FQZ_NS];
     uint32_t chunk0[FQZ_NS];
@@ -247,7 +259,8 @@ struct SegLds {
     uint32_t misc[8];
 };
 
-// exclusive scan over the 256 threads of up to four values at once; *tot = totals.  sh: 16 words
+// exclusive scan over the NW * 64 threads of the workgroup of up to four values at once; *tot = totals.  sh: 4 * NW words
+template <int NW>
 __device__ __forceinline__ void seg_scan4(const uint32_t v[4], uint32_t *sh, uint32_t ex[4], uint32_t tot[4])
 {
     const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -257,19 +270,18 @@ __device__ __forceinline__ void seg_scan4(const uint32_t v[4], uint32_t *sh, uin
     __syncthreads();
     if (l == 63) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) sh[4 * c + w] = inc[c];
+        for (int c = 0; c < 4; c++) sh[NW * c + w] = inc[c];
     }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         uint32_t base = 0, t2 = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) { const uint32_t s = sh[4 * c + k]; if (k < w) base += s; t2 += s; }
+        for (uint32_t k = 0; k < (uint32_t)NW; k++) { const uint32_t x = sh[NW * c + k]; if (k < w) base += x; t2 += x; }
         ex[c] = base + inc[c] - v[c];
         tot[c] = t2;
     }
 }
-
 __device__ __forceinline__ void seg_fallback(EncInfo *info, BlockPlan *plans, uint32_t blk)
 {
     atomicOr(&plans[blk].fallback, 1u);
@@ -281,9 +293,8 @@ __device__ __forceinline__ void seg_fallback(EncInfo *info, BlockPlan *plans, ui
 // tables (oracle hdr_write_sequences with n = 1: extra bits of the three codes, then the three initial states, the end mark).
 // M < SEG_LEN_MIN is left to the general coder (the oracle judges such a block against its 66-bit bound and stores it Raw).
 #define SEG_LEN_MIN 20u
-__device__ __forceinline__ void seg_len_frame_block(const uint8_t *part, uint32_t M, uint8_t *slot, uint32_t *cs)
+__device__ __forceinline__ void seg_len_frame_block(const uint8_t *part, uint32_t M, uint8_t *slot, uint32_t *cs) // (one thread calls it)
 {
-    if (threadIdx.x) return;
     const uint32_t ml = M - 4, mlb = ml - 3;
     const uint32_t mc = mlb < 128 ? (uint32_t)c_hml_code[mlb] : (uint32_t)highbit32_d(mlb) + 36u;
     const uint32_t lc = 4, oc = 2, ofv = 4 + 3;
@@ -309,18 +320,26 @@ __device__ __forceinline__ void seg_len_frame_block(const uint8_t *part, uint32_
 
 // MODE 0: encode.  MODE 1: DetectEncoding (quality.go:22-49) - the minimum quality byte of the segment goes to info->min_qual.
 template <int MODE>
-__device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint32_t n_text, EncInfo *info, SegInfo *seg, BlockPlan *plans, uint32_t rpb,
-                              uint8_t *__restrict__ sarena, size_t sarena_cap, uint8_t *__restrict__ slots, uint32_t page_cap, uint32_t *__restrict__ csize, uint32_t chunk_cap,
-                              uint32_t *__restrict__ ehbuf, uint32_t eh_cap, SegHdrJob *__restrict__ jobs, uint32_t *__restrict__ hord, uint32_t *__restrict__ hlist, uint32_t hcap,
-                              uint4 *__restrict__ hmap, uint4 *__restrict__ xmap, uint32_t group_cap, uint32_t g)
+__device__ __forceinline__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint32_t n_text, EncInfo *info, SegInfo *seg, BlockPlan *plans, uint32_t rpb,
+                              uint8_t *__restrict__ sarena, uint8_t *__restrict__ slots, uint32_t *__restrict__ csize, uint32_t *__restrict__ ehbuf,
+                              SegHdrJob *__restrict__ jobs, uint32_t hcap, uint4 *__restrict__ hmap, uint4 *__restrict__ xmap, uint32_t g,
+                              unsigned long long *stamps = nullptr)
 {
+    // stamps != nullptr (FQZ_DBG_STAMPS, diagnostic runs only): thread 0 records s_memtime at every phase boundary, 16 words a segment
+#define SEG_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)g * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    SEG_STAMP(0);
     SegInfo *sg = &seg[g];
     const uint32_t a = sg->text_off, e = seg[g + 1].text_off, rec0 = sg->rec0, nrec = seg[g + 1].rec0 - rec0;
     const uint32_t blk = rpb ? rec0 / rpb : 0;
+    const uint32_t n_segs = info->n_segs;
     SegTabs &T = S.u.tab;
-    auto zero_out = [&]() {
-        if (MODE == 0 && t < FQZ_NS) { sg->raw[t] = 0; sg->chunk0[t] = 0; sg->slot0[t] = 0; sg->a_off[t] = 0; sg->foff[t] = 0; sg->flen[t] = 0; }
+    auto zero_out = [&]() { // nothing to code: the segment's entries in the job and group lists say so
+        if (MODE == 0 && t < FQZ_NS) {
+            sg->raw[t] = 0; sg->chunk0[t] = 0; sg->slot0[t] = 0; sg->a_off[t] = 0; sg->foff[t] = 0; sg->flen[t] = 0;
+            xmap[t * n_segs + g] = make_uint4(0, 0, 0, 0);
+            if (t == 0) { sg->hx = 0; hmap[g] = make_uint4(g, 0, 0, 0); SegHdrJob j = {0, 0, 0, 0, 0, g, 0, 0}; jobs[g] = j; }
+        }
     };
     if (nrec == 0) { zero_out(); return; }
     if (MODE == 0 && (nrec > SEG_RMAX || e - a > SEG_SPAN_MAX)) { zero_out(); if (t == 0) seg_fallback(info, plans, blk); return; }
@@ -336,17 +355,29 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
     // ---- P1a: newline bitmap of [a, e), a u16 per aligned 16-byte piece, in the (still empty) arena
     const uint32_t base = a & ~15u, np = (e - base + 15) >> 4;
     uint16_t *bm = (uint16_t *)S.arena;
-    for (uint32_t i = t; i < ((np + 15) & ~15u) + 16; i += SEG_NT) {
-        uint32_t m = 0;
-        if (i < np) {
-            const uint32_t off = base + 16 * i;
-            m = seg_nl_mask16(load_text16(text, off, n_text));
-            if (off < a) m &= ~((1u << (a - off)) - 1u);
-            if (off + 16 > e) m &= (1u << (e - off)) - 1u;
+    // (eight loads a thread in flight: a load that is waited for right away costs a memory round trip a round)
+    for (uint32_t i0 = 0; i0 < ((np + 15) & ~15u) + 16; i0 += 8 * SEG_NT) {
+        uint4 v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t i = i0 + u * SEG_NT + t;
+            v[u] = i < np ? load_text16(text, base + 16 * i, n_text) : make_uint4(0, 0, 0, 0);
         }
-        bm[i] = (uint16_t)m;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t i = i0 + u * SEG_NT + t;
+            uint32_t m = 0;
+            if (i < np) {
+                const uint32_t off = base + 16 * i;
+                m = seg_nl_mask16(v[u]);
+                if (off < a) m &= ~((1u << (a - off)) - 1u);
+                if (off + 16 > e) m &= (1u << (e - off)) - 1u;
+            }
+            if (i < ((np + 15) & ~15u) + 16) bm[i] = (uint16_t)m;
+        }
     }
     __syncthreads();
+    SEG_STAMP(1);
     // ---- P1b: line starts: a thread per 16 pieces (256 text bytes), one scan of the counts per 256 threads
     const uint32_t ng = (np + 15) >> 4;
     uint32_t carry = 0;
@@ -363,7 +394,7 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
         for (int d = 0; d < 8; d++) c += __popc(w8[d]);
         const uint32_t v4[4] = {c, 0, 0, 0};
         uint32_t ex[4], tot[4];
-        seg_scan4(v4, S.sh, ex, tot);
+        seg_scan4<SEG_NW>(v4, S.sh, ex, tot);
         uint32_t idx = carry + ex[0] + 1; // newline j (1-based) starts line j
 #pragma unroll
         for (int d = 0; d < 8; d++) {
@@ -384,9 +415,11 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
         if (t == 0) { if (MODE == 0) seg_fallback(info, plans, blk); else info->status = FQZ_E_HIP; }
         return;
     }
+    SEG_STAMP(2);
     // ---- P2: the records (parser.go:136-183 nextInto): line lengths without '\n' and one '\r', the checks, stream sizes
     uint32_t sz_tot[4] = {0, 0, 0, 0};
     uint32_t pq_min = 0xFFFFFFFFu, pq_max = 0, pq_carry = 0;
+    uint32_t p_or = 0; // OR of the plus payload lengths of this thread's records
     for (uint32_t r0 = 0; r0 < nrec; r0 += SEG_NT) {
         const uint32_t r = r0 + t;
         uint32_t v[4] = {0, 0, 0, 0}, L = 0, H = 0, P = 0;
@@ -418,12 +451,13 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
         }
         if (MODE == 1) continue;
         uint32_t ex[4], tot[4];
-        seg_scan4(v, S.sh, ex, tot);
+        seg_scan4<SEG_NW>(v, S.sh, ex, tot);
         const uint32_t pq = (L + 15) >> 4;
         if (r < nrec) {
             T.oseq[r] = (uint16_t)(sz_tot[0] + ex[0]); T.oqual[r] = (uint16_t)(sz_tot[1] + ex[1]);
             T.ohdr[r] = (uint16_t)(sz_tot[2] + ex[2]); T.oplus[r] = (uint16_t)(sz_tot[3] + ex[3]);
             T.ncnt[r] = 0;
+            p_or |= P;
             pq_min = pq < pq_min ? pq : pq_min; pq_max = pq > pq_max ? pq : pq_max;
         }
 #pragma unroll
@@ -431,6 +465,7 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
         __syncthreads();
     }
     if (MODE == 1) return;
+    SEG_STAMP(3);
     // sizes that cannot be held: the block goes the FQZ-H2 way (FQZ-S1: a segment's six parts, each rounded up to 16, fit SEG_ARENA)
     const uint32_t len_bytes = 4 * nrec;
     const uint32_t r_seq = 0, r_qual = r_seq + ((sz_tot[0] + 15) & ~15u), r_hdr = r_qual + ((sz_tot[1] + 15) & ~15u), r_plus = r_hdr + ((sz_tot[2] + 15) & ~15u),
@@ -444,11 +479,15 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
     // piece table of the quality / bases lines: uniform (every record the same count: fixed-length reads) or by search over ipq
     {
         const uint32_t mn = wave_min(pq_min), mx = 0xFFFFFFFFu - wave_min(0xFFFFFFFFu - pq_max);
+        const unsigned long long anyp = __ballot(p_or != 0);
         __syncthreads(); // (the bitmap in the arena is dead from here on; S.sh free)
-        if (lane == 0) { S.sh[wave] = mn; S.sh[4 + wave] = mx; }
+        if (lane == 0) { S.sh[wave] = mn; S.sh[SEG_NW + wave] = mx; S.sh[2 * SEG_NW + wave] = anyp ? 1u : 0u; }
         __syncthreads();
-        const uint32_t gmn = min(min(S.sh[0], S.sh[1]), min(S.sh[2], S.sh[3])), gmx = max(max(S.sh[4], S.sh[5]), max(S.sh[6], S.sh[7]));
+        uint32_t gmn = 0xFFFFFFFFu, gmx = 0, gp = 0;
+#pragma unroll
+        for (uint32_t w2 = 0; w2 < SEG_NW; w2++) { gmn = min(gmn, S.sh[w2]); gmx = max(gmx, S.sh[SEG_NW + w2]); gp |= S.sh[2 * SEG_NW + w2]; }
         pq_min = gmn; pq_max = gmx;
+        p_or = gp; // 0: every plus line is bare -> the plus part is all zero bytes
         __syncthreads();
     }
     const uint32_t uni = (pq_min == pq_max && pq_min > 0) ? pq_min : 0u;
@@ -459,7 +498,7 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
             const uint32_t pq = r < nrec ? ((uint32_t)T.L[r] + 15) >> 4 : 0u;
             const uint32_t v4[4] = {pq, 0, 0, 0};
             uint32_t ex[4], tot[4];
-            seg_scan4(v4, S.sh, ex, tot);
+            seg_scan4<SEG_NW>(v4, S.sh, ex, tot);
             if (r < nrec) T.ipq[r] = (uint16_t)(pc + ex[0] + pq);
             pc += tot[0];
             __syncthreads();
@@ -469,67 +508,117 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
     const uint32_t Tq = uni ? uni * nrec : pq_carry;
     const uint32_t qoff = info->qual_off;
     __syncthreads();
+    SEG_STAMP(4);
     // ---- P3: split.  Bases and qualities piece by piece (16 text bytes of one line per lane and round, as k_split does);
     //      headers, plus lines and lengths a record per thread.
+    for (uint32_t i = t; i < 4 * 256; i += SEG_NT) (&S.qhist[0][0])[i] = 0;
+    __syncthreads();
     const float inv_uni = uni ? 1.0f / (float)uni : 0.0f;
-    for (uint32_t p0 = 0; p0 < Tq; p0 += SEG_NT) {
-        const uint32_t p = p0 + t;
-        const bool on = p < Tq;
-        uint32_t i = 0, k = 0;
-        if (on) {
-            if (uni) {
-                uint32_t q = (uint32_t)(((float)p + 0.5f) * inv_uni);
-                if (q * uni > p) q--;
-                if ((q + 1) * uni <= p) q++;
-                i = q; k = p - q * uni;
-            } else { // smallest i with ipq[i] > p
-                uint32_t lo = 0, hi = nrec - 1;
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)T.ipq[mid] > p) hi = mid; else lo = mid + 1; }
-                i = lo;
-                k = p - ((uint32_t)T.ipq[i] - (((uint32_t)T.L[i] + 15) >> 4));
-            }
-        }
-        uint32_t x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0}, have = 0, srcq = 0, dseq = 0, dqual = 0;
-        if (on) {
-            const uint32_t Li = T.L[i];
-            const uint32_t src = a + T.lt[4 * i + 1];
-            srcq = a + T.lt[4 * i + 3];
-            dseq = r_seq + T.oseq[i] + 4 * k;
-            dqual = r_qual + T.oqual[i] + 16 * k;
-            have = Li - 16 * k < 16 ? Li - 16 * k : 16;
-            load_piece(text, (size_t)src + 16 * k, n_text, x);
-            load_piece(text, (size_t)srcq + 16 * k, n_text, y);
-        }
-        // the byte in front of a quality piece is the last byte of the previous lane's piece (same read, piece k - 1); lane 0 fetches it
-        const uint32_t left = (uint32_t)__shfl_up((int)(y[3] >> 24), 1, WAVE);
-        if (on) {
-            uint32_t out = 0, nn = 0;
+#define SEG_SR 4u // rounds of 256 pieces per trip: 2 x SEG_SR loads a thread in flight before the first is used
+    for (uint32_t p0 = 0; p0 < Tq; p0 += SEG_SR * SEG_NT) {
+        uint32_t x[SEG_SR][4], y[SEG_SR][4], have[SEG_SR], srcq[SEG_SR], dseq[SEG_SR], dqual[SEG_SR], ri[SEG_SR], rk[SEG_SR];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t v = x[q], in_read = 0x80808080u;
-                if (have < 4u * q + 4) { // bytes past the read pack as 0
-                    const uint32_t hv = have > 4u * q ? have - 4u * q : 0;
-                    v = hv ? v & ((1u << (8 * hv)) - 1) : 0;
-                    in_read = hv ? in_read >> (8 * (4 - hv)) : 0;
+        for (uint32_t u = 0; u < SEG_SR; u++) {
+            const uint32_t p = p0 + u * SEG_NT + t;
+            const bool on = p < Tq;
+            uint32_t i = 0, k = 0;
+            if (on) {
+                if (uni) {
+                    uint32_t q = (uint32_t)(((float)p + 0.5f) * inv_uni);
+                    if (q * uni > p) q--;
+                    if ((q + 1) * uni <= p) q++;
+                    i = q; k = p - q * uni;
+                } else { // smallest i with ipq[i] > p
+                    uint32_t lo = 0, hi = nrec - 1;
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)T.ipq[mid] > p) hi = mid; else lo = mid + 1; }
+                    i = lo;
+                    k = p - ((uint32_t)T.ipq[i] - (((uint32_t)T.L[i] + 15) >> 4));
                 }
-                const uint32_t vmask = acgt_mask(v);
-                out |= pack4(v, vmask) << (8 * q);
-                nn += __popc(~vmask & in_read);
             }
-            uint32_t prev = k ? (lane ? left : (uint32_t)text[srcq + 16 * k - 1]) : qoff;
+            ri[u] = i; rk[u] = k;
+            have[u] = 0; srcq[u] = 0; dseq[u] = 0; dqual[u] = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) { const uint32_t yq = y[q]; y[q] = sub_bytes(yq, (yq << 8) | (prev & 0xFF)); prev = yq >> 24; }
-            const uint32_t nb = (have + 3) >> 2;
-            uint8_t *o = S.arena + dseq;
-            if (nb == 4) store_u32_unaligned(o, out);
-            else {
-                if (nb & 2) { const uint16_t v16 = (uint16_t)out; __builtin_memcpy(o, &v16, 2); }
-                if (nb & 1) o[nb & 2] = (uint8_t)(out >> (8 * (nb & 2)));
+            for (int q = 0; q < 4; q++) x[u][q] = y[u][q] = 0;
+            if (on) {
+                const uint32_t Li = T.L[i];
+                const uint32_t src = a + T.lt[4 * i + 1];
+                srcq[u] = a + T.lt[4 * i + 3];
+                dseq[u] = r_seq + T.oseq[i] + 4 * k;
+                dqual[u] = r_qual + T.oqual[i] + 16 * k;
+                have[u] = Li - 16 * k < 16 ? Li - 16 * k : 16;
+                load_piece(text, (size_t)src + 16 * k, n_text, x[u]);
+                load_piece(text, (size_t)srcq[u] + 16 * k, n_text, y[u]);
             }
-            store_piece(S.arena + dqual, y, have);
-            if (nn) atomicAdd(&T.ncnt[i], nn);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < SEG_SR; u++) {
+            const uint32_t p = p0 + u * SEG_NT + t;
+            const bool on = p < Tq;
+            const uint32_t k = rk[u], i = ri[u];
+            // the byte in front of a quality piece is the last byte of the previous lane's piece (same read, piece k - 1); lane 0 fetches it
+            const uint32_t left = (uint32_t)__shfl_up((int)(y[u][3] >> 24), 1, WAVE);
+            if (on) {
+                uint32_t out = 0, nn = 0;
+                const uint32_t hv0 = have[u];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t v = x[u][q], in_read = 0x80808080u;
+                    if (hv0 < 4u * q + 4) { // bytes past the read pack as 0
+                        const uint32_t hv = hv0 > 4u * q ? hv0 - 4u * q : 0;
+                        v = hv ? v & ((1u << (8 * hv)) - 1) : 0;
+                        in_read = hv ? in_read >> (8 * (4 - hv)) : 0;
+                    }
+                    const uint32_t vmask = acgt_mask(v);
+                    out |= pack4(v, vmask) << (8 * q);
+                    nn += __popc(~vmask & in_read);
+                }
+                uint32_t prev = k ? (lane ? left : (uint32_t)text[srcq[u] + 16 * k - 1]) : qoff;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const uint32_t yq = y[u][q]; y[u][q] = sub_bytes(yq, (yq << 8) | (prev & 0xFF)); prev = yq >> 24; }
+                const uint32_t nb = (hv0 + 3) >> 2;
+                uint8_t *o = S.arena + dseq[u];
+                if (nb == 4) store_u32_unaligned(o, out);
+                else {
+                    if (nb & 2) { const uint16_t v16 = (uint16_t)out; __builtin_memcpy(o, &v16, 2); }
+                    if (nb & 1) o[nb & 2] = (uint8_t)(out >> (8 * (nb & 2)));
+                }
+                store_piece(S.arena + dqual[u], y[u], hv0);
+                if (nn) atomicAdd(&T.ncnt[i], nn);
+            }
+            // ---- histogram of the quality part, per 16 KiB chunk, from the registers: zeros (most delta bytes) are counted with
+            //      SWAR compares and added once per wave, the rest a byte at a time with LDS atomics
+            {
+                const uint32_t hv0 = on ? have[u] : 0u;
+                const uint32_t qo = dqual[u] - r_qual, ck = qo >> 14; // (FQZ_CHUNK = 2^14)
+                const bool straddle = on && ((qo & (FQZ_CHUNK - 1)) + hv0 > FQZ_CHUNK);
+                uint32_t nz = 0;
+                if (on && !straddle) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t valid = hv0 >= 4u * q + 4 ? 0x80808080u : (hv0 > 4u * q ? (0x80808080u >> (8 * (4 * q + 4 - hv0))) : 0u);
+                        const uint32_t z = zero_bytes(y[u][q]) & valid;
+                        nz += __popc(z);
+                        uint32_t other = valid & ~z;
+                        while (other) {
+                            const int bit = __ffs(other) - 1; // 7, 15, 23 or 31
+                            other &= other - 1;
+                            atomicAdd(&S.qhist[ck][(y[u][q] >> (bit - 7)) & 0xFF], 1u);
+                        }
+                    }
+                } else if (straddle) { // (once per chunk boundary) byte by byte
+                    for (uint32_t bi = 0; bi < hv0; bi++) atomicAdd(&S.qhist[(qo + bi) >> 14][(y[u][bi >> 2] >> (8 * (bi & 3))) & 0xFF], 1u);
+                }
+                // zeros: one add per wave when all its pieces lie in one chunk (nearly always)
+                const uint32_t ck0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ck);
+                const bool mixed = __ballot(on && !straddle && ck != ck0) != 0;
+                if (!mixed) {
+                    const uint32_t tot = wave_sum(nz);
+                    if (lane == 0 && tot) atomicAdd(&S.qhist[ck0 & 3][0], tot);
+                } else if (nz) atomicAdd(&S.qhist[ck][0], nz);
+            }
         }
     }
+    SEG_STAMP(5);
     for (uint32_t r = t; r < nrec; r += SEG_NT) {
         const uint32_t H = T.H[r], P = T.P[r], L = T.L[r];
         *(uint32_t *)(S.arena + r_len + 4 * r) = L; // compress.go:501
@@ -565,6 +654,7 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
         }
     }
     __syncthreads();
+    SEG_STAMP(6);
     // ---- P3b: N positions: [u16 n][n x u16 position] per record (compress.go:477-498); positions below 65536 only - every read
     //      of a qualifying segment is shorter than that
     uint32_t np_tot = 0;
@@ -573,7 +663,7 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
         const uint32_t nn = r < nrec ? T.ncnt[r] : 0u;
         const uint32_t v4[4] = {r < nrec ? 2 + 2 * nn : 0u, 0, 0, 0};
         uint32_t ex[4], tot[4];
-        seg_scan4(v4, S.sh, ex, tot);
+        seg_scan4<SEG_NW>(v4, S.sh, ex, tot);
         if (r < nrec) T.onpos[r] = (uint16_t)((np_tot + ex[0]) & 0xFFFFu);
         if (r < nrec && np_tot + ex[0] > 0xFFFFu) np_tot = 0x10000000u; // (far beyond the arena: caught below)
         np_tot += tot[0];
@@ -589,7 +679,7 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
         const uint16_t n16 = (uint16_t)T.ncnt[r];
         *(uint16_t *)(S.arena + r_npos + T.onpos[r]) = n16; // (2-aligned: every record takes an even number of bytes)
     }
-    for (uint32_t r = wave; r < nrec; r += SEG_NT / 64) { // a wave per record that has any: its pieces lane by lane
+    for (uint32_t r = wave; np_tot != 2 * nrec && r < nrec; r += SEG_NT / 64) { // a wave per record that has any: its pieces lane by lane
         const uint32_t nn = T.ncnt[r];
         if (!nn) continue;
         const uint32_t L = T.L[r], src = a + T.lt[4 * r + 1];
@@ -620,64 +710,59 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
             done += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
     }
+    // all u32 lengths equal: the lengths part is 4 literal bytes and one match (FQZ-S1)
+    uint32_t len_same = 0;
+    {
+        uint32_t diff = 0;
+        for (uint32_t r = t; r < nrec; r += SEG_NT) diff |= (uint32_t)T.L[r] ^ (uint32_t)T.L[0];
+        const unsigned long long any = __ballot(diff != 0);
+        __syncthreads();
+        if (lane == 0) S.sh[wave] = any ? 1u : 0u;
+        __syncthreads();
+        uint32_t anyd = 0;
+#pragma unroll
+        for (uint32_t w2 = 0; w2 < SEG_NW; w2++) anyd |= S.sh[w2];
+        len_same = !anyd && len_bytes >= SEG_LEN_MIN ? 1u : 0u;
+    }
     __syncthreads();
-    // ---- P4: slots, arena space, headers jobs; the parts go to the stream arena (content checksums, headers model)
+    SEG_STAMP(7);
+    // ---- P4: where things go.  Everything a segment owns in HBM sits at a place its number gives (csize / xsum entries, slot pool
+    //      pages, stream arena, headers chunk ordinal = g, record-offset table): 15 000 workgroups bumping shared counters spent more
+    //      time in those atomics than in the coding.  Only a headers part longer than one chunk (rare) takes its further chunk
+    //      ordinals from a counter.
     if (t == 0) {
         const uint32_t raw[FQZ_NS] = {sz_tot[0], sz_tot[1], sz_tot[2], sz_tot[3], np_tot, len_bytes};
         const uint32_t reg[FQZ_NS] = {r_seq, r_qual, r_hdr, r_plus, r_npos, r_len};
-        uint32_t ids = 0, pages = 0, abytes = 0;
-        for (int s = 0; s < FQZ_NS; s++) {
-            ids += s == S_HDR ? (raw[s] ? 1u : 0u) : (raw[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
-            pages += s == S_HDR ? 0u : seg_pages(raw[s], s);
-            abytes += (raw[s] + 15) & ~15u;
-        }
-        uint32_t id = atomicAdd(&info->n_chunks, ids), pg = atomicAdd(&info->pages_used, pages);
-        const unsigned long long ao = atomicAdd(&info->sarena_used, (unsigned long long)abytes);
-        bool ok = id + ids <= chunk_cap && pg + pages <= page_cap && ao + abytes <= sarena_cap;
-        // headers: chunk jobs for the model (their zstd blocks: the headers' own slots and sizes, by chunk ordinal)
+        uint32_t id = g * SEG_IDS, pg = g * SEG_SLOT_PAGES, apos = g * SEG_ASTRIDE;
+        bool ok = true;
         const uint32_t nch_h = (raw[S_HDR] + FQZ_CHUNK - 1) / FQZ_CHUNK;
-        uint32_t o0 = 0, eo = 0;
-        if (ok && nch_h) {
-            o0 = atomicAdd(&info->n_hchunks, nch_h);
-            eo = atomicAdd(&info->eh_used, nrec + 1);
-            if (o0 + nch_h > hcap || eo + nrec + 1 > eh_cap) ok = false;
-        }
-        if (!ok) atomicCAS(&info->status, 0, FQZ_E_TOO_LARGE);
-        uint32_t apos = (uint32_t)ao;
+        uint32_t ox = 0; // ordinals of the headers chunks 1.. (chunk 0 has ordinal g)
+        if (nch_h > 1) { ox = atomicAdd(&info->n_hchunks, nch_h - 1); if (ox + nch_h - 1 > hcap) { ok = false; atomicCAS(&info->status, 0, FQZ_E_TOO_LARGE); } }
         for (int s = 0; s < FQZ_NS; s++) {
             S.raw[s] = raw[s]; S.reg[s] = reg[s];
             S.chunk0[s] = id;
-            S.slot0[s] = s == S_HDR ? o0 : pg;
+            S.slot0[s] = pg;
             S.a_off[s] = apos;
-            id += s == S_HDR ? (raw[s] ? 1u : 0u) : (raw[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
-            pg += s == S_HDR ? 0u : seg_pages(raw[s], s);
+            id += s == S_SEQ ? 1u : (raw[s] + FQZ_CHUNK - 1) / FQZ_CHUNK;
+            pg += seg_pages(raw[s], s);
             apos += (raw[s] + 15) & ~15u;
             sg->raw[s] = raw[s]; sg->chunk0[s] = S.chunk0[s]; sg->slot0[s] = S.slot0[s]; sg->a_off[s] = S.a_off[s]; sg->foff[s] = 0; sg->flen[s] = 0;
-            atomicAdd(&info->stream_raw[s], (unsigned long long)raw[s]);
         }
+        sg->hx = ox;
         S.misc[0] = ok ? 1u : 0u;
-        S.misc[1] = eo;
         if (ok) {
             for (uint32_t k = 0; k < nch_h; k++) {
+                const uint32_t o = k ? ox + k - 1 : g;
                 SegHdrJob j;
-                j.a_off = S.a_off[S_HDR]; j.e_off = eo; j.nrec = nrec; j.c0 = k * FQZ_CHUNK;
+                j.a_off = S.a_off[S_HDR]; j.e_off = g * (SEG_RMAX + 1); j.nrec = nrec; j.c0 = k * FQZ_CHUNK;
                 j.mk = raw[S_HDR] - k * FQZ_CHUNK < FQZ_CHUNK ? raw[S_HDR] - k * FQZ_CHUNK : FQZ_CHUNK;
-                j.chunk = o0 + k; j.pad0 = j.pad1 = 0;
-                jobs[o0 + k] = j;
-                hord[o0 + k] = o0 + k; // (the headers kernels map chunk -> ordinal: here they are the same)
-                hlist[o0 + k] = o0 + k;
+                j.chunk = o; j.slot_off = S.slot0[S_HDR] * SEG_PAGE + k * FQZ_SLOT; j.cs = S.chunk0[S_HDR] + k;
+                jobs[o] = j;
             }
-            if (nch_h) {
-                const uint32_t hg = atomicAdd(&info->n_hgroups, 1u);
-                if (hg < group_cap) hmap[hg] = make_uint4(o0, S.a_off[S_HDR], raw[S_HDR] | ((uint32_t)S_HDR << 28), 0u);
-                else atomicCAS(&info->status, 0, FQZ_E_TOO_LARGE);
-            }
-            for (int s = 0; s < FQZ_NS; s++) { // every frame for the checksums
-                if (!raw[s]) continue;
-                const uint32_t xg = atomicAdd(&info->n_xgroups, 1u);
-                if (xg < group_cap) xmap[xg] = make_uint4(S.chunk0[s], S.a_off[s], raw[s] | ((uint32_t)s << 28), 0u);
-                else atomicCAS(&info->status, 0, FQZ_E_TOO_LARGE);
-            }
+            // (groups: one list entry per segment and stream, empty ones included - k_entropy_hdr_seg / k_xxh skip them)
+            hmap[g] = make_uint4(g, S.a_off[S_HDR], raw[S_HDR] | ((uint32_t)S_HDR << 28), ox);
+            // (stream-major: the 16 frames a wave of k_xxh hashes side by side are of one stream, so of about one length)
+            for (int s = 0; s < FQZ_NS; s++) xmap[s * n_segs + g] = make_uint4(S.chunk0[s], S.a_off[s], raw[s] | ((uint32_t)s << 28), 0u);
         }
     }
     __syncthreads();
@@ -698,21 +783,12 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
             const uint4 *src = (const uint4 *)(S.arena + S.reg[S_SEQ]);
             for (uint32_t i = t; i < nb16; i += SEG_NT) dst[i] = src[i];
         }
-        const uint32_t eo = S.misc[1];
-        if (S.raw[S_HDR]) for (uint32_t r = t; r <= nrec; r += SEG_NT) ehbuf[eo + r] = T.ohdr[r];
-    }
-    // all u32 lengths equal: the lengths part is 4 literal bytes and one match (FQZ-S1); decided before the tables are given up
-    uint32_t len_same = 0;
-    {
-        uint32_t diff = 0;
-        for (uint32_t r = t; r < nrec; r += SEG_NT) diff |= (uint32_t)T.L[r] ^ (uint32_t)T.L[0];
-        const unsigned long long any = __ballot(diff != 0);
-        __syncthreads();
-        if (lane == 0) S.sh[wave] = any ? 1u : 0u;
-        __syncthreads();
-        len_same = !(S.sh[0] | S.sh[1] | S.sh[2] | S.sh[3]) && len_bytes >= SEG_LEN_MIN ? 1u : 0u;
+        if (S.raw[S_HDR]) for (uint32_t r = t; r <= nrec; r += SEG_NT) ehbuf[g * (SEG_RMAX + 1) + r] = T.ohdr[r];
+        // (the lengths block of a segment of equal read lengths: one thread's few dependent steps, beside the copies)
+        if (len_same && t == SEG_NT - 1) seg_len_frame_block(S.arena + S.reg[S_LEN], S.raw[S_LEN], slots + (size_t)S.slot0[S_LEN] * SEG_PAGE, csize + S.chunk0[S_LEN]);
     }
     __syncthreads(); // the record tables are dead: their LDS becomes the entropy coder's
+    SEG_STAMP(8);
     // ---- P5: entropy stage from LDS: qualities, plus lines, N positions, lengths
     const int order[4] = {S_QUAL, S_PLUS, S_NPOS, S_LEN};
 #pragma unroll 1
@@ -722,21 +798,37 @@ __device__ void seg_workgroup(SegLds &S, const uint8_t *__restrict__ text, uint3
         if (!M) continue;
         uint8_t *slot0 = slots + (size_t)S.slot0[s] * SEG_PAGE;
         uint32_t *cs0 = csize + S.chunk0[s];
-        if (s == S_LEN && len_same) { seg_len_frame_block(S.arena + S.reg[s], M, slot0, cs0); continue; }
-        entropy_encode_group<false>(S.u.ent, S.arena + S.reg[s], M, 0u, slot0, cs0);
+        if (s == S_LEN && len_same) continue; // (written beside the copies above)
+        if ((s == S_PLUS && !p_or) || (s == S_NPOS && np_tot == 2 * nrec)) {
+            // a part of zero bytes (bare plus lines; no N anywhere): an RLE block per 16 KiB, as the coder would find out after a
+            // histogram and a dozen barriers (fqz_entropy_dev.h: same_mask)
+            const uint32_t nch = (M + FQZ_CHUNK - 1) / FQZ_CHUNK;
+            if (t < nch) {
+                const uint32_t mk = M - t * FQZ_CHUNK < FQZ_CHUNK ? M - t * FQZ_CHUNK : FQZ_CHUNK;
+                const uint32_t bh = (t + 1 == nch ? 1u : 0u) | (1u << 1) | (mk << 3);
+                *(uint32_t *)(slot0 + (size_t)t * FQZ_SLOT) = bh & 0xFFFFFFu; // (the repeated byte: 0)
+                cs0[t] = 4;
+            }
+            continue;
+        }
+        // (diagnostic runs: the coder's own phase stamps of the quality part go behind the segments' stamps)
+        seg_encode_part(S.u.ent, S.arena + S.reg[s], sarena + S.a_off[s], M, slot0, cs0, s == S_QUAL ? &S.qhist[0][0] : nullptr,
+                        (stamps && s == S_QUAL) ? stamps + ((size_t)gridDim.x + g) * 16 : nullptr);
         __syncthreads();
+        SEG_STAMP(9 + q);
     }
+    SEG_STAMP(13);
+#undef SEG_STAMP
 }
 
-__global__ __launch_bounds__(SEG_NT) void k_seg_encode(const uint8_t *__restrict__ text, uint32_t n_text, EncInfo *info, SegInfo *seg, BlockPlan *plans, uint32_t rpb,
-                                                      uint8_t *__restrict__ sarena, size_t sarena_cap, uint8_t *__restrict__ slots, uint32_t page_cap, uint32_t *__restrict__ csize, uint32_t chunk_cap,
-                                                      uint32_t *__restrict__ ehbuf, uint32_t eh_cap, SegHdrJob *__restrict__ jobs, uint32_t *__restrict__ hord,
-                                                      uint32_t *__restrict__ hlist, uint32_t hcap, uint4 *__restrict__ hmap, uint4 *__restrict__ xmap, uint32_t group_cap)
+__global__ __launch_bounds__(SEG_NT, 4) void k_seg_encode(const uint8_t *__restrict__ text, uint32_t n_text, EncInfo *info, SegInfo *seg, BlockPlan *plans, uint32_t rpb,
+                                                      uint8_t *__restrict__ sarena, uint8_t *__restrict__ slots, uint32_t *__restrict__ csize, uint32_t *__restrict__ ehbuf,
+                                                      SegHdrJob *__restrict__ jobs, uint32_t hcap, uint4 *__restrict__ hmap, uint4 *__restrict__ xmap, unsigned long long *stamps)
 {
     __shared__ SegLds S;
     const uint32_t g = blockIdx.x;
     if (g >= info->n_segs || info->status) return;
-    seg_workgroup<0>(S, text, n_text, info, seg, plans, rpb, sarena, sarena_cap, slots, page_cap, csize, chunk_cap, ehbuf, eh_cap, jobs, hord, hlist, hcap, hmap, xmap, group_cap, g);
+    seg_workgroup<0>(S, text, n_text, info, seg, plans, rpb, sarena, slots, csize, ehbuf, jobs, hcap, hmap, xmap, g, stamps);
 }
 
 // encoder.DetectEncoding (quality.go:22-49) over the first block: the segments of block 0
@@ -745,7 +837,7 @@ __global__ __launch_bounds__(SEG_NT) void k_seg_detect(const uint8_t *__restrict
     __shared__ SegLds S;
     const uint32_t g = blockIdx.x;
     if (info->status || !info->n_blocks || g >= plans[0].n_seg) return;
-    seg_workgroup<1>(S, text, n_text, info, seg, plans, rpb, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, g);
+    seg_workgroup<1>(S, text, n_text, info, seg, plans, rpb, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, g);
 }
 
 // the headers model (fqz_hdrlz.h) over the headers chunks the segment workgroups announced
@@ -756,7 +848,54 @@ __global__ __launch_bounds__(256) void k_hdr_model_seg(const EncInfo *info, cons
     const uint32_t o = blockIdx.x;
     if (o >= info->n_hchunks || o >= hcap || info->status) return;
     const SegHdrJob j = jobs[o];
+    if (!j.mk) { if (threadIdx.x == 0) { HdrSide z = {0, 0, 0, 0}; side[o] = z; } return; } // a segment without records
     hdr_model_chunk(S, sarena + j.a_off, ehbuf + j.e_off, 0u, j.nrec, j.c0, j.mk, hseq + (size_t)o * HDR_MAX_SEQ, hlit + (size_t)o * FQZ_CHUNK, &side[o], hhist + (size_t)o * 256);
+}
+
+// the entropy stage over the literals of a segment's headers part (k_entropy_hdr with the segment path's numbering: chunk 0 of
+// the part has the segment's number as its ordinal in the side buffers, further chunks the ordinals hmap[g].w ...)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_entropy_hdr_seg(const EncInfo *info, const uint4 *hmap, const SegInfo *seg, const uint8_t *sarena,
+                                                         uint8_t *slots, uint32_t *csize, uint32_t hcap, const uint8_t *hlit, const HdrSide *side, const uint16_t *hhist)
+{
+    __shared__ __attribute__((aligned(16))) EntropyLds S;
+    __shared__ HdrGroup H;
+    const uint32_t g = blockIdx.x;
+    if (g >= info->n_segs || info->status) return;
+    const uint4 gd = hmap[g];
+    const uint32_t M = gd.z & 0xFFFFFFu, t = threadIdx.x;
+    if (!M) return;
+    const uint8_t *src = sarena + gd.y;
+    if (t < (M + FQZ_CHUNK - 1) / FQZ_CHUNK) {
+        const uint32_t mk = M - t * FQZ_CHUNK < FQZ_CHUNK ? M - t * FQZ_CHUNK : FQZ_CHUNK, o = t ? gd.w + t - 1 : g;
+        HdrSide sd = {0, mk, 0, 0};
+        if (o < hcap) sd = side[o];
+        H.nseq[t] = sd.nseq; H.n_lit[t] = sd.nseq ? sd.n_lit : mk;
+        H.lit[t] = sd.nseq ? hlit + (size_t)o * FQZ_CHUNK : src + (size_t)t * FQZ_CHUNK;
+        H.hist[t] = hhist + (size_t)(o < hcap ? o : 0) * 256;
+    }
+    __syncthreads();
+    entropy_encode_group<true>(S, src, M, 0u, slots + (size_t)seg[g].slot0[S_HDR] * SEG_PAGE, &csize[seg[g].chunk0[S_HDR]], 0, nullptr, &H);
+}
+
+// k_hdr_patch with the segment path's numbering: the Sequences_Section of a headers chunk goes behind its literals
+__global__ __launch_bounds__(64) void k_hdr_patch_seg(const EncInfo *info, const SegHdrJob *jobs, uint32_t hcap, const HdrSide *side, const uint8_t *hsec, uint8_t *slots, uint32_t *csize)
+{
+    const uint32_t o = blockIdx.x, lane = threadIdx.x;
+    if (o >= info->n_hchunks || o >= hcap || info->status) return;
+    const HdrSide sd = side[o];
+    if (!sd.nseq) return;
+    const SegHdrJob j = jobs[o];
+    uint8_t *slot = slots + j.slot_off;
+    const uint32_t bh = slot[0] | ((uint32_t)slot[1] << 8) | ((uint32_t)slot[2] << 16);
+    if (((bh >> 1) & 3) != 2) return; // the chunk became a Raw block
+    const uint32_t prov = csize[j.cs], ssz = sd.sec_len;
+    const uint8_t *sec = hsec + (size_t)o * HDR_SEQ_CAP;
+    for (uint32_t i = lane; i < ssz; i += 64) slot[prov + i] = sec[i];
+    if (lane == 0) {
+        const uint32_t fin = prov + ssz, nb = (bh & 7u) | ((fin - 3u) << 3);
+        slot[0] = (uint8_t)nb; slot[1] = (uint8_t)(nb >> 8); slot[2] = (uint8_t)(nb >> 16);
+        csize[j.cs] = fin;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -767,7 +906,7 @@ __device__ __forceinline__ uint32_t seg_fh(uint32_t M) { return M < 256u ? 6u : 
 
 // a workgroup per block: the frame lengths of its segments (from the compressed sizes of their zstd blocks), their places inside
 // the payloads, the payload lengths.  csize is read as the coders left it (not scanned).
-__global__ __launch_bounds__(256) void k_seg_sizes(EncInfo *info, BlockPlan *plans, SegInfo *seg, const uint32_t *__restrict__ csize, const uint32_t *__restrict__ hcsize)
+__global__ __launch_bounds__(256) void k_seg_sizes(EncInfo *info, BlockPlan *plans, SegInfo *seg, const uint32_t *__restrict__ csize)
 {
     __shared__ uint32_t sh[16];
     const uint32_t b = blockIdx.x, t = threadIdx.x;
@@ -787,15 +926,14 @@ __global__ __launch_bounds__(256) void k_seg_sizes(EncInfo *info, BlockPlan *pla
                 const uint32_t nch = (M + FQZ_CHUNK - 1) / FQZ_CHUNK;
                 uint32_t body = 0;
                 if (s == S_SEQ) body = M + 3 * nch;
-                else if (s == S_HDR) for (uint32_t k = 0; k < nch; k++) body += hcsize[sg->slot0[s] + k];
                 else for (uint32_t k = 0; k < nch; k++) body += csize[sg->chunk0[s] + k];
                 fl[s] = seg_fh(M) + body + 4;
             }
         }
         uint32_t ex[4], tot[4], ex2[4], tot2[4];
         const uint32_t va[4] = {fl[0], fl[1], fl[2], fl[3]}, vb[4] = {fl[4], fl[5], rw[0] + rw[1], rw[2] + rw[3] + rw[4] + rw[5]};
-        seg_scan4(va, sh, ex, tot);
-        seg_scan4(vb, sh, ex2, tot2);
+        seg_scan4<4>(va, sh, ex, tot);
+        seg_scan4<4>(vb, sh, ex2, tot2);
         if (i < ns) {
             sg->foff[0] = run[0] + ex[0]; sg->foff[1] = run[1] + ex[1]; sg->foff[2] = run[2] + ex[2]; sg->foff[3] = run[3] + ex[3];
             sg->foff[4] = run[4] + ex2[0]; sg->foff[5] = run[5] + ex2[1];
@@ -822,6 +960,7 @@ __global__ __launch_bounds__(256) void k_seg_sizes(EncInfo *info, BlockPlan *pla
         }
         orig = rawt[S_QUAL];
         p->orig_seq = orig;
+        for (int s = 0; s < FQZ_NS; s++) if (rawt[s]) atomicAdd(&info->stream_raw[s], (unsigned long long)rawt[s]);
     }
 }
 
@@ -903,7 +1042,7 @@ __device__ __forceinline__ void seg_copy(uint8_t *dst, const uint8_t *src, uint3
 // a workgroup per segment: its frames -> their places: frame header, the zstd blocks from their slots (packed bases: a Raw block
 // header in front of each 16 KiB of the part's bytes), the content checksum; and the segment's entry in each payload's index
 __global__ __launch_bounds__(256) void k_seg_compact(const EncInfo *info, const BlockPlan *plans, const SegInfo *seg, const uint8_t *__restrict__ slots, const uint32_t *__restrict__ csize,
-                                                     const uint8_t *__restrict__ hslots, const uint32_t *__restrict__ hcsize, const uint32_t *__restrict__ xsum, uint8_t *__restrict__ out)
+                                                     const uint32_t *__restrict__ xsum, uint8_t *__restrict__ out)
 {
     const uint32_t g = blockIdx.x, t = threadIdx.x;
     if (info->status || info->seg_fallback || g >= info->n_segs) return;
@@ -942,10 +1081,6 @@ __global__ __launch_bounds__(256) void k_seg_compact(const EncInfo *info, const 
                 if (t == 0) { dst[0] = (uint8_t)bh; dst[1] = (uint8_t)(bh >> 8); dst[2] = (uint8_t)(bh >> 16); }
                 seg_copy(dst + 3, slots + (size_t)sg->slot0[s] * SEG_PAGE + (size_t)k * FQZ_CHUNK, mk);
                 dst += 3 + mk;
-            } else if (s == S_HDR) {
-                const uint32_t n = hcsize[sg->slot0[s] + k];
-                seg_copy(dst, hslots + (size_t)(sg->slot0[s] + k) * FQZ_SLOT, n);
-                dst += n;
             } else {
                 const uint32_t n = csize[sg->chunk0[s] + k];
                 seg_copy(dst, slots + (size_t)sg->slot0[s] * SEG_PAGE + (size_t)k * FQZ_SLOT, n);

@@ -569,7 +569,7 @@ static void encode_block_job(enc_job *j)
     j->out = NULL; j->out_len = 0;
     j->err = fqzo_split_block(j->text, j->recs, j->n_rec, j->enc, &s);
     if (j->err) return;
-    if (j->entropy == 0 && j->framing == 0) {
+    if (j->entropy == 0 && j->framing == 1) {
         const int r = encode_block_segments(j, &s);
         if (r) { fqzo_streams_free(&s); if (r < 0) j->err = r; return; }
     }

@@ -200,8 +200,8 @@ typedef struct {
                              * file whose first batch another process saw (multi-GPU sharding: rank 0 detects and broadcasts) */
     int block_index;        /* entropy == 2 only: 1 = append the block table behind the last block (include/fqz.h: FQZ-R1's optional
                              * on-disk block index) */
-    int framing;            /* entropy == 0 only: 0 = FQZ-S1 segment framing for every block that qualifies (the default of the HIP
-                             * encoder), 1 = FQZ-H2 group framing always (FQZ_ENC_LEGACY=1 there) */
+    int framing;            /* entropy == 0 only: 0 = FQZ-H2 group framing (the default of the HIP encoder), 1 = FQZ-S1 segment framing for
+                             * every block that qualifies (experimental: FQZ_BATCH_SEG / FQZ_ENC_SEG=1 there) */
 } fqzo_options;
 
 size_t fqzo_compress_bound(size_t n_bytes);

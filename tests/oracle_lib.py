@@ -276,8 +276,8 @@ def huf_code_lengths(counts):
 
 
 def compress(fastq, block_size=0, workers=1, batch_records=0, entropy=0, force_encoding=0, block_index=0, framing=0) -> bytes:
-    """compress.Compress on a memory buffer (bytes or numpy uint8 array).  framing: 0 = FQZ-S1 segment framing for blocks that
-    qualify (what the HIP encoder writes by default), 1 = FQZ-H2 group framing always (FQZ_ENC_LEGACY=1 there)."""
+    """compress.Compress on a memory buffer (bytes or numpy uint8 array).  framing: 0 = FQZ-H2 group framing (what the HIP encoder
+    writes by default), 1 = FQZ-S1 segment framing for blocks that qualify (experimental; FQZ_BATCH_SEG / FQZ_ENC_SEG=1 there)."""
     a = np.frombuffer(fastq, dtype=np.uint8) if not isinstance(fastq, np.ndarray) else fastq
     cap = lib().fqzo_compress_bound(a.size)
     if batch_records:  # tiny blocks: 36-byte block headers and six frame headers per block dwarf the library's bound

@@ -63,7 +63,7 @@ def _qual_payload(z, block=0):
 def test_oracle_v3_round_trips_and_is_smaller_on_skewed_qualities():
     for name, text in _cases():
         z3 = O.compress(text, entropy=2)
-        z2 = O.compress(text, framing=1)  # (version 3 is the group framing with another quality coder)
+        z2 = O.compress(text)
         assert z3[4] == 3 and z2[4] == 2, name
         assert O.decompress(z3) == text, name
         # everything but the quality payload is the version-2 payload
@@ -71,7 +71,7 @@ def test_oracle_v3_round_trips_and_is_smaller_on_skewed_qualities():
             h2, h3 = struct.unpack_from("<9I", z2, 10), struct.unpack_from("<9I", z3, 10)
             assert h2[:2] + h2[3:] == h3[:2] + h3[3:], name
     text = make_fastq(20000, seed=44)
-    z2, z3 = O.compress(text, framing=1), O.compress(text, entropy=2)
+    z2, z3 = O.compress(text), O.compress(text, entropy=2)
     q2, q3 = struct.unpack_from("<9I", z2, 10)[2], struct.unpack_from("<9I", z3, 10)[2]
     assert q3 < 0.7 * q2, (q2, q3)  # order-0 entropy instead of >= 1 bit a symbol
 

@@ -1,5 +1,6 @@
 """FQZ-S1 smoke: GPU .fqz == oracle .fqz for a handful of shapes; both decoders read it.  Run on the GPU box."""
-import sys, time
+import os, sys, time
+os.environ["FQZ_ENC_SEG"] = "1"  # the experimental segment path for every entry point
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
 import fastqpacker_amd as fq
@@ -18,7 +19,7 @@ cases = [("tiny", make_fastq(3, seed=1)), ("3000", make_fastq(3000, seed=1)), ("
          ("short reads", make_fastq(5000, seed=5, min_len=1, max_len=40)), ("empty", b""), ("20000", make_fastq(20000, seed=44))]
 bad = 0
 for name, t in cases:
-    want = O.compress(t)
+    want = O.compress(t, framing=1)
     try:
         got = compress.Compress(t)
     except Exception as e:
