@@ -35,6 +35,7 @@ struct DecBlock {
     uint32_t frame_base[FQZ_NS];    // first entry of the payload in the frame table
     uint32_t samp_off[FQZ_NS];      // offset in d_in of the record samples of the payload's index (stream offsets of records 64, 128, ...); 0: none
     uint32_t seq_scratch;           // arena offset of the scratch of the headers stream's blocks with sequences (DSEQ_STRIDE each; 0: none)
+    uint32_t seq_scratch_len;       // the same for the lengths stream (a chunk of equal read lengths is one match)
 };
 
 struct DecFrame {
@@ -761,9 +762,10 @@ __global__ __launch_bounds__(256) void k_dec_index(const uint8_t *in, DecInfo *i
                     const uint32_t c_huf = fmt <= 1 ? ((lh >> 14) & 0x3FFu) : (fmt == 2 ? ((lh >> 18) & 0x3FFFu) : (((lh >> 22) | ((uint32_t)q[7] << 10)) & 0x3FFFFu));
                     const uint32_t lit_total = need + (lt2 == 0 ? r_plain : (lt2 == 1 ? 1u : c_huf));
                     const uint32_t regen = lt2 <= 1 ? r_plain : r_huf;
-                    if (bs >= need && lit_total + 2 <= bs && regen <= mk && s == S_HDR && b->seq_scratch && q[3 + lit_total] != 0) {
-                        // sequences behind the literals (headers model, fqz_decode_seq.h): the literals go to the block's scratch
-                        d.dst_off = b->seq_scratch + c * DSEQ_STRIDE;
+                    const uint32_t scr = s == S_HDR ? b->seq_scratch : (s == S_LEN ? b->seq_scratch_len : 0u);
+                    if (bs >= need && lit_total + 2 <= bs && regen <= mk && scr && q[3 + lit_total] != 0) {
+                        // sequences behind the literals (headers model, lengths: fqz_decode_seq.h): the literals go to the block's scratch
+                        d.dst_off = scr + c * DSEQ_STRIDE;
                         d.regen = regen;
                         d.seq_len = bs - lit_total;
                     } else if (bs < need || lit_total + 1 != bs || regen != mk) bad = true;
@@ -1964,10 +1966,17 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     bool any_seq = false; // scratch for the blocks with sequences of our own headers streams (fqz_decode_seq.h), behind the streams
     for (uint32_t b = 0; b < nb; b++) {
         hb[b].seq_scratch = 0;
-        if (!hb[b].indexed[S_HDR] || !hb[b].n_chunks[S_HDR]) continue;
-        hb[b].seq_scratch = (uint32_t)arena;
-        arena += (unsigned long long)hb[b].n_chunks[S_HDR] * DSEQ_STRIDE;
-        any_seq = true;
+        hb[b].seq_scratch_len = 0;
+        if (hb[b].indexed[S_HDR] && hb[b].n_chunks[S_HDR]) {
+            hb[b].seq_scratch = (uint32_t)arena;
+            arena += (unsigned long long)hb[b].n_chunks[S_HDR] * DSEQ_STRIDE;
+            any_seq = true;
+        }
+        if (hb[b].indexed[S_LEN] && hb[b].n_chunks[S_LEN]) {
+            hb[b].seq_scratch_len = (uint32_t)arena;
+            arena += (unsigned long long)hb[b].n_chunks[S_LEN] * DSEQ_STRIDE;
+            any_seq = true;
+        }
     }
     // NumRecords comes from the (untrusted) block header: tie it to the decoded stream sizes before anything is sized from it.
     // Order as blockReader.writeRecord meets them (compress.go:944-975): length, N positions, header.

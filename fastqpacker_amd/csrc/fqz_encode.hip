@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPla
     const BlockPlan *p = &plans[b];
     const uint32_t off = c * FQZ_CHUNK;
     if (s == S_SEQ) csize[chunk] = 3u + (p->len[s] - off < FQZ_CHUNK ? p->len[s] - off : FQZ_CHUNK); // Raw block: header + bytes
-    if (s == S_HDR) { // headers chunks are modelled first (fqz_hdrlz.h): ordinal = slot in the side buffers
+    if (s == S_HDR || s == S_LEN) { // headers and lengths chunks are modelled first (fqz_hdrlz.h): ordinal = slot in the side buffers
         const uint32_t o = atomicAdd(&info->n_hchunks, 1u);
         hord[chunk] = o;
         if (o < hcap) hlist[o] = chunk;
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPla
     const uint32_t x = atomicAdd(&info->n_xgroups, 1u); // any order: groups are independent
     if (x < group_cap) xmap[x] = d;
     if (s == S_SEQ) return;
-    if (s == S_HDR) {
+    if (s == S_HDR || s == S_LEN) {
         const uint32_t g = atomicAdd(&info->n_hgroups, 1u);
         if (g < group_cap) hmap[g] = d;
         return;
@@ -917,6 +917,12 @@ __global__ __launch_bounds__(256) void k_hdr_model(const EncInfo *info, const Bl
     if (o >= info->n_hchunks || o >= hcap) return;
     const uint32_t chunk = hlist[o];
     const BlockPlan *p = &plans[cinfo[chunk] & 0xFFFFFFu];
+    if ((cinfo[chunk] >> 24) == S_LEN) { // a chunk of the lengths stream: all values equal -> one match (len_model_chunk)
+        const uint32_t lc0 = (chunk - p->chunk_base[S_LEN]) * FQZ_CHUNK, llen = p->len[S_LEN];
+        len_model_chunk(S.hist, arena + p->a_off[S_LEN] + lc0, llen - lc0 < FQZ_CHUNK ? llen - lc0 : FQZ_CHUNK, hseq + (size_t)o * HDR_MAX_SEQ, hlit + (size_t)o * FQZ_CHUNK,
+                        &side[o], hhist + (size_t)o * 256);
+        return;
+    }
     const uint32_t c0 = (chunk - p->chunk_base[S_HDR]) * FQZ_CHUNK, len = p->len[S_HDR];
     const uint32_t mk = len - c0 < FQZ_CHUNK ? len - c0 : FQZ_CHUNK;
     hdr_model_chunk(S, arena + p->a_off[S_HDR], Eh, p->rec0, p->nrec, c0, mk, hseq + (size_t)o * HDR_MAX_SEQ, hlit + (size_t)o * FQZ_CHUNK, &side[o], hhist + (size_t)o * 256);
@@ -1503,7 +1509,7 @@ static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes
     uint4 *rmap = (flags & FQZ_BATCH_V3) ? hmap + group_cap : nullptr; // container version 3: the qualities are coded by k_rans
     // side buffers of the headers model: per headers chunk its sequences, literals, Sequences_Section (fqz_hdrlz.h).  Sized for
     // a quarter of the text being headers; a batch with more is relaunched with the exact need (fqz_enc_finish)
-    uint32_t hcap = (uint32_t)(n / (4ull * FQZ_CHUNK)) + 2 * e.block_cap + 64;
+    uint32_t hcap = (uint32_t)(n / (4ull * FQZ_CHUNK)) + 2 * e.block_cap + 64; // (the lengths chunks - 4 bytes a read - ride along)
     if (e.hcap_need > hcap && e.hcap_need_bytes == n_bytes) hcap = e.hcap_need; // (a relaunch of the batch that reported the need)
     e.hcap_need = 0;
     if (e.hcap_per_mb > 0) { // a header-heavy input: the batches that follow one that overflowed are sized by its density
@@ -1547,7 +1553,7 @@ static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes
     // The headers model fills the chip like the entropy coder does (both are bound by instruction issue: side by side they
     // only take turns), so it runs in line; what follows it - the FSE state chains, the bit packing, the entropy stage over
     // the literals - is a chain of short, latency-bound kernels that runs beside the entropy coder of the other streams.
-    const uint32_t hgroup_cap = hcap / FQZ_GROUP + e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + e.block_cap + 8 : group_cap;
+    const uint32_t hgroup_cap = hcap / FQZ_GROUP + 2 * e.block_cap + 8 < group_cap ? hcap / FQZ_GROUP + 2 * e.block_cap + 8 : group_cap; // (headers and lengths groups)
     // container version 3: the qualities' rANS coder (a chain of short steps a wave) goes first on its stream, beside everything
     // that follows; the content checksums - they need the streams only, nPos included - have slack until k_compact.  (A stream of
     // its own for the coder bought nothing: HIP maps streams onto four hardware queues by default, and a fifth stream shares

@@ -284,6 +284,34 @@ __device__ void hdr_model_chunk(HdrModelLds &S, const uint8_t *__restrict__ stre
     if (t == 0) { side->nseq = nseq; side->n_lit = mk - matched; side->sec_len = 0; side->pad = 0; }
 }
 
+// The lengths stream (u32 per read, compress.go:501) through the same machinery: a chunk whose values are all equal - fixed-length
+// reads - is 4-periodic, which an order-0 coder cannot see; it becomes its first value as literals + ONE sequence {4 literals,
+// match of mk - 4 bytes at offset 4} (oracle fqzo_entropy_encode_stream_v, stream 5).  Any other chunk: no sequences, its
+// histogram for the entropy stage.  sh: 256 words of LDS.
+__device__ void len_model_chunk(uint32_t *sh, const uint8_t *__restrict__ chunk, uint32_t mk, uint2 *__restrict__ hseq, uint8_t *__restrict__ hlit, HdrSide *side,
+                                uint16_t *__restrict__ hhist)
+{
+    const uint32_t t = threadIdx.x;
+    const uint32_t *w = (const uint32_t *)chunk; // (16-byte aligned: the stream starts aligned and chunks are 16 KiB)
+    const uint32_t nw = mk >> 2, w0 = nw ? w[0] : 0u;
+    uint32_t diff = 0;
+    for (uint32_t i = t; i < nw; i += 256) diff |= w[i] ^ w0;
+    sh[t] = 0;
+    const bool periodic = !__syncthreads_or(diff != 0) && mk >= 20 && (mk & 3) == 0;
+    if (periodic) {
+        if (t == 0) {
+            hseq[0] = make_uint2(4u | ((mk - 4) << 16), 4u);
+            for (int q = 0; q < 4; q++) { const uint32_t b = (w0 >> (8 * q)) & 0xFF; hlit[q] = (uint8_t)b; sh[b]++; }
+            side->nseq = 1; side->n_lit = 4; side->sec_len = 0; side->pad = 0;
+        }
+    } else {
+        for (uint32_t i = t; i < mk; i += 256) atomicAdd(&sh[chunk[i]], 1u);
+        if (t == 0) { side->nseq = 0; side->n_lit = mk; side->sec_len = 0; side->pad = 0; }
+    }
+    __syncthreads();
+    hhist[t] = (uint16_t)sh[t];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Sequences_Section of a chunk (count, modes byte = Predefined x 3, backward bitstream in ZSTD_encodeSequences order).
 // The only serial part is the three FSE state chains (literal length, match length, offset codes, each walked from the

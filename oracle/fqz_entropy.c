@@ -864,9 +864,10 @@ size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, in
         for (uint32_t k = 1; k <= ns; k++) put32le(sp + 4 * k, rs[64 * k]);
     }
     const size_t G = (size_t)FQZO_GROUP * FQZO_CHUNK;
-    if (stream != 2) { free(rs); rs = NULL; } /* (only the headers are modelled) */
+    if (stream != 2) { free(rs); rs = NULL; } /* (only the headers are modelled against their records) */
     hseq *sqbuf = rs ? (hseq *)malloc(sizeof(hseq) * FQZO_GROUP * HDR_MAX_SEQ) : NULL;
     uint8_t *litbuf = rs ? (uint8_t *)malloc(G) : NULL;
+    hseq lseq[FQZO_GROUP]; /* lengths stream: a chunk of equal u32 values = its first value + one match at offset 4 */
     for (size_t off = 0; off < n; off += G) {
         const size_t M = n - off < G ? n - off : G;
         op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
@@ -887,7 +888,25 @@ size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, in
             }
             body = encode_group_chunks(ch, nch, 0, op);
         } else if (version == 3 && stream == 1) body = encode_group_rans(src + off, M, op); /* FQZ-R1 */
-        else body = encode_group_ex(src + off, M, 1, stream == 0, op);
+        else if (stream == 5) {
+            /* u32 read lengths (compress.go:501): fixed-length reads make the stream 4-periodic, which an order-0 coder cannot see
+             * (1 bit a byte at best) and zstd level 1 codes as one match.  Per 16 KiB chunk (a zstd block of its own, as for the
+             * headers): all values equal and at least 20 bytes -> literals = the first value, one sequence {4 literals, match of
+             * mk - 4 bytes at offset 4} on the predefined tables; any other chunk is plain. */
+            gchunk ch[FQZO_GROUP];
+            int nch = 0;
+            for (size_t co = 0; co < M; co += FQZO_CHUNK, nch++) {
+                const uint32_t mk = (uint32_t)(M - co < FQZO_CHUNK ? M - co : FQZO_CHUNK);
+                const uint8_t *c = src + off + co;
+                ch[nch].raw = ch[nch].lit = c; ch[nch].mk = ch[nch].n_lit = mk; ch[nch].sq = NULL; ch[nch].nseq = 0;
+                if (mk >= 20 && (mk & 3) == 0) {
+                    int same = 1;
+                    for (uint32_t i = 4; i < mk && same; i++) same = c[i] == c[i - 4];
+                    if (same) { lseq[nch].ll = 4; lseq[nch].ml = mk - 4; lseq[nch].off = 4; ch[nch].sq = &lseq[nch]; ch[nch].nseq = 1; ch[nch].n_lit = 4; }
+                }
+            }
+            body = encode_group_chunks(ch, nch, 0, op);
+        } else body = encode_group_ex(src + off, M, 1, stream == 0, op);
         /* the index lists the size of every zstd block of the group */
         for (size_t q = 0; q < body;) {
             const uint32_t bh = op[q] | ((uint32_t)op[q + 1] << 8) | ((uint32_t)op[q + 2] << 16);
