@@ -37,6 +37,7 @@ def parse_args():
                     "3 = FQZ-R1 (rANS-coded qualities, SURVEY 8 f-4; not readable by the stock decoder)")
     ap.add_argument("--no-v3", action="store_true", help="skip the supplementary container_v3 reading (profiling runs: one kind of launch per kernel)")
     ap.add_argument("--inflight", type=int, default=3, help="batches in flight for the supplementary pipelined figure (0 = skip)")
+    ap.add_argument("--no-supp", action="store_true", help="skip the supplementary readings (config 2 as 10 M reads, config 5's shape)")
     ap.add_argument("--dry-ranks", action="store_true", help="CPU rehearsal of the N-rank path (gloo, no GPU, no codec): every rank runs the "
                     "launcher, the rendezvous, the block-offset all-gather and the max-over-ranks timing on made-up block sizes")
     return ap.parse_args()
@@ -151,6 +152,28 @@ def cpu_baseline(text_np, want_seconds=20.0):
     v_all, d_all, ratio, ok_all, reps_all = timed(cut_all, cores, want_seconds * 0.6)
     cut_one = sample(min(total_blocks, 3))                              # W = 1: ~100 MB keeps the leg within seconds
     v_one, d_one, _, ok_one, reps_one = timed(cut_one, 1, want_seconds * 0.4)
+    # per-stream ratios of the CPU pipeline's file: compressed sizes from its block headers, pre-entropy sizes by
+    # the stream layouts from the decoded record count and read lengths of the same sample
+    stream_ratio = None
+    try:
+        z = O.compress(cut_all, workers=cores, entropy=entropy)
+        comp = [0] * 6
+        pos, nrec = 10, 0
+        while pos + 36 <= len(z):
+            h = [int.from_bytes(z[pos + 4 * i: pos + 4 * i + 4], "little") for i in range(9)]
+            nrec += h[0]
+            for i in range(6):
+                comp[i] += h[1 + i]
+            pos += 36 + sum(h[1:7])
+        lines = cut_all.size  # raw sizes: seq ceil(L/4), qual L, headers 2 + H, plus 2 + P, nPos 2 + 2n (no N in this workload), lengths 4
+        L = 150
+        hdr_bytes = int(cut_all.size - nrec * (2 * L + 6))  # text = (H + 2) + (L + 1) + (P + 2) + (L + 1) per record, P = 0
+        raw = [nrec * ((L + 3) // 4), nrec * L, hdr_bytes + 2 * nrec, 2 * nrec, 2 * nrec, 4 * nrec]
+        names = ["seq", "qual", "headers", "plus", "npos", "lengths"]
+        stream_ratio = {names[i]: (round(raw[i] / comp[i], 3) if comp[i] else None) for i in range(6)}
+        del lines
+    except Exception:
+        pass
     ent = "libzstd-%d level 1 entropy stage" % O.lib().fqzo_libzstd_version() if entropy else "its own Huffman entropy stage"
     jobs = int(cut_all.size // (rec_bytes * 100000)) + 1
     return {
@@ -158,7 +181,7 @@ def cpu_baseline(text_np, want_seconds=20.0):
         "sample": "%d MB (%d blocks of 100k reads = %d block jobs for %d worker threads: %.0f %% of the cores can be busy) of the same "
                   "synthetic FASTQ, 1 verified + %d timed pass(es), oracle C pipeline (CPU restatement, not the reference Go binary) with %s"
                   % (cut_all.size // 1000000, jobs, jobs, cores, 100.0 * min(1.0, jobs / cores), reps_all, ent),
-        "decode_MBps": round(d_all, 1), "ratio": round(ratio, 3), "roundtrip_ok": bool(ok_all and ok_one),
+        "decode_MBps": round(d_all, 1), "ratio": round(ratio, 3), "stream_ratio": stream_ratio, "roundtrip_ok": bool(ok_all and ok_one),
         "w1": {"value": round(v_one, 1), "unit": "MB/s", "cores": 1, "decode_MBps": round(d_one, 1),
                "sample": "%d MB, 1 verified + %d timed pass(es), one worker thread" % (cut_one.size // 1000000, reps_one)},
     }
@@ -471,6 +494,67 @@ def main():
             del d_out3
         except Exception as e:
             out["container_v3"] = {"error": repr(e)}
+    # ---- supplementary: BASELINE config 2 in its '10 M reads' reading (3.5 GB: two device batches back to back) and
+    # config 5's shape on one GPU (35-301 bp, 5 % N, Phred+64, 1 GB).  Same library calls as the headline; not the headline.
+    if world == 1 and len(batches) == 1 and not a.no_supp and not a.reads and a.container == 2:
+        supp = {}
+        try:
+            del d_backs, fqz_devs
+            torch.cuda.empty_cache()
+
+            def run_batches(texts, enc_id, steps=3):
+                dts = [torch.from_numpy(t).to(dev) for t in texts]
+                dos = [torch.empty(int(lib().fqz_encode_bound(t.size)) // 2 + (1 << 20), dtype=torch.uint8, device=dev) for t in texts]
+                rs = [BatchResult() for _ in texts]
+
+                def enc():
+                    for i, t in enumerate(texts):
+                        fq._lib.check(lib().fqz_encode_batch_dev(ctx.handle, dts[i].data_ptr(), t.size, RPB, enc_id, fq.BATCH_FINAL, dos[i].data_ptr(), dos[i].numel(),
+                                                                 C.byref(rs[i]), None, None, 0, sptr))
+                enc()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    enc()
+                torch.cuda.synchronize()
+                et = (time.perf_counter() - t0) / steps
+                zs = [dos[i][: int(rs[i].out_len)].clone() for i in range(len(texts))]
+                bk = [torch.empty(t.size + 4096, dtype=torch.uint8, device=dev) for t in texts]
+                ds = [BatchResult() for _ in texts]
+
+                def dec():
+                    for i in range(len(texts)):
+                        fq._lib.check(lib().fqz_decode_batch_dev(ctx.handle, zs[i].data_ptr(), zs[i].numel(), 2, enc_id, bk[i].data_ptr(), bk[i].numel(), C.byref(ds[i]), sptr))
+                dec()
+                ok = all(bool(ds[i].out_len == texts[i].size and torch.equal(bk[i][: texts[i].size], dts[i])) for i in range(len(texts)))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    dec()
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t0) / 2
+                nb = sum(t.size for t in texts)
+                return {"bytes": int(nb), "device_batches": len(texts), "encode_MBps": round(nb / et / 1e6, 1), "decode_MBps": round(nb / dt2 / 1e6, 1),
+                        "ratio": round(nb / sum(int(r.out_len) for r in rs), 3), "roundtrip_bit_exact": bool(ok)}
+
+            # config 2, '10 M reads': whole 100k-read blocks per device batch (< 2 GiB each)
+            total_reads, per_batch, r0, texts = 10_000_000, (int(1.9e9) // 351 // RPB) * RPB, 0, []
+            while r0 < total_reads:
+                nr = min(per_batch, total_reads - r0)
+                t_np, wrote = compress.synth_fastq(nr, first_record=r0, quality_profile=a.quality_profile)
+                texts.append(t_np)
+                r0 += nr
+            supp["config2_reads_1e7"] = dict(run_batches(texts, fq.ENCODING_PHRED33), workload="synthetic 150 bp Phred+33, 10 M reads (BASELINE configs[1], '10 M reads' reading)")
+            del texts
+            # config 5's shape on one GPU
+            t5, _ = compress.synth_fastq(2_400_000, min_len=35, max_len=301, n_permille=50, phred=64)
+            t5 = t5[:1_000_000_000]
+            k5 = bytes(t5[-8192:]).rfind(b"\n@SIM:")
+            t5 = t5[: t5.size - 8192 + k5 + 1]
+            supp["config5_shape_1gpu"] = dict(run_batches([t5], fq.ENCODING_PHRED64), workload="synthetic 35-301 bp, 5 % N, Phred+64, 1 GB on ONE GPU (BASELINE configs[4] is this shape on 8)")
+        except Exception as e:
+            supp["error"] = repr(e)
+        out["supplementary"] = supp
     if not a.no_cpu and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(batches[0])

@@ -648,6 +648,52 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
                                                uint32_t *E, uint32_t estride, const BlockPlan *__restrict__ plans, uint32_t rpb,
                                                uint8_t *__restrict__ arena)
 {
+#ifndef SPLIT_STAGE
+#define SPLIT_STAGE 1 // 1: the pieces of a trip go through a per-wave LDS stage and leave as aligned 16-byte units (0: straight to the arena)
+#endif
+    // Staging (VERDICT r2 #2a: 222 bytes per wave store of a possible 1024).  The pieces of one trip - 2 x 64 of them, in stream
+    // order - cover ONE contiguous range of the quality stream and one of the packed bases (the records of a wave follow each other
+    // in the arena; only a block boundary breaks the run, and such a trip is stored the old way).  They are written into the stage
+    // at their offset from an aligned arena address; whole 16-byte units then leave with one store a lane, the bytes of the last,
+    // incomplete unit stay in the stage as the head of the next trip, and what is left when the wave moves on (or in front of the
+    // first aligned address of a run) leaves byte by byte.  Wave-local: no workgroup barrier.
+    __shared__ __attribute__((aligned(16))) uint8_t s_q[4][SPLIT_ROUNDS * 1024 + 48], s_s[4][SPLIT_ROUNDS * 256 + 48];
+    struct Run { uint32_t a0, n; }; // stage byte 0 <-> arena address a0 (16-aligned); n bytes staged and not yet stored (< 16 between trips)
+    Run rq = {0, 0}, rs = {0, 0};
+    const uint32_t wl = (threadIdx.x >> 6) & 3u;
+    auto run_flush = [&](uint8_t *st, Run &r, uint32_t ln) { // what is staged leaves byte by byte (every lane calls)
+        if (r.n) {
+            wave_lds_sync();
+            for (uint32_t b = ln; b < r.n; b += 64) arena[r.a0 + b] = st[b];
+            wave_lds_sync();
+            r.n = 0;
+        }
+    };
+    // after the lanes have written their pieces at st[pos0 + ...] (pos0 = offset of `start` from r.a0): store what is whole
+    auto run_store = [&](uint8_t *st, Run &r, uint32_t end, uint32_t head, uint32_t ln) {
+        // end: bytes in the stage; head: bytes at the front that are NOT ours (a fresh run that starts inside a 16-byte unit)
+        wave_lds_sync();
+        uint32_t u0 = 0;
+        if (head) { // the first unit holds foreign bytes in front: ours leave byte by byte
+            const uint32_t lim = end < 16 ? end : 16;
+            if (ln >= head && ln < lim) arena[r.a0 + ln] = st[ln];
+            u0 = 1;
+            if (end <= 16) { // nothing beyond the first unit: the run continues behind it with nothing staged
+                wave_lds_sync();
+                r.a0 += end; r.n = 0; // (a0 is no longer aligned: the next trip starts a fresh run from its own address)
+                return;
+            }
+        }
+        const uint32_t nu = end >> 4;
+        for (uint32_t i = u0 + ln; i < nu; i += 64) *(uint4 *)(arena + r.a0 + 16 * i) = *(const uint4 *)(st + 16 * i);
+        const uint32_t rem = end & 15u;
+        uint4 tail = make_uint4(0, 0, 0, 0);
+        if (rem && ln == 0) tail = *(const uint4 *)(st + 16 * nu);
+        wave_lds_sync();
+        if (rem && ln == 0) *(uint4 *)st = tail;
+        wave_lds_sync();
+        r.a0 += 16 * nu; r.n = rem;
+    };
     const uint32_t n_rec = info->n_rec, qoff = info->qual_off;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
     const uint32_t *Eseq = E + (size_t)S_SEQ * estride, *Equal = E + (size_t)S_QUAL * estride, *Ehdr = E + (size_t)S_HDR * estride;
@@ -735,7 +781,7 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
         };
         // stores and atomics, after every load of the trip has been consumed: stores count in vmcnt like loads (gfx9), and a
         // wait for the next round's loads behind them would wait for their acknowledgements too
-        auto commit = [&](PieceJob &J) {
+        [[maybe_unused]] auto commit = [&](PieceJob &J) {
             if (J.on) {
                 const uint32_t have = J.have, k = J.k, out = J.out;
                 const uint32_t nb = (have + 3) >> 2;
@@ -759,10 +805,87 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
 #pragma unroll
             for (uint32_t u = 0; u < SPLIT_ROUNDS; u++)
                 if (base + u * WAVE < Tq) compute(J[u]);
+#if SPLIT_STAGE
+            {
+                // the trip's range of the quality stream and of the packed bases: from its first piece to the end of its last one
+                uint32_t totq = 0, tots = 0, q_first = 0, s_first = 0, q_last = 0, s_last = 0;
+                bool any = false;
+#pragma unroll
+                for (uint32_t u = 0; u < SPLIT_ROUNDS; u++) {
+                    if (!(base + u * WAVE < Tq)) continue;
+                    const unsigned long long act = __ballot(J[u].on);
+                    if (!act) continue;
+                    const int l0 = __ffsll((long long)act) - 1, l1 = 63 - __clzll((long long)act);
+                    const uint32_t hq = J[u].on ? J[u].have : 0u, hs = J[u].on ? (J[u].have + 3) >> 2 : 0u;
+                    const uint32_t packed = wave_incl_scan(hq | (hs << 16));
+                    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)packed, 63);
+                    totq += tot & 0xFFFFu; tots += tot >> 16;
+                    const uint32_t aq = J[u].dstq + 16 * J[u].k, as = J[u].dst + 4 * J[u].k;
+                    if (!any) { q_first = (uint32_t)__builtin_amdgcn_readlane((int)aq, l0); s_first = (uint32_t)__builtin_amdgcn_readlane((int)as, l0); any = true; }
+                    q_last = (uint32_t)__builtin_amdgcn_readlane((int)(aq + hq), l1);
+                    s_last = (uint32_t)__builtin_amdgcn_readlane((int)(as + hs), l1);
+                }
+                const bool contiguous = any && q_last - q_first == totq && s_last - s_first == tots;
+#pragma unroll
+                for (uint32_t u = 0; u < SPLIT_ROUNDS; u++) { // what does not go through the stage
+                    if (!(base + u * WAVE < Tq) || !J[u].on) continue;
+                    if (J[u].beyond) report_error(info, g * 64 + J[u].i, 4, FQZ_E_LONG_N);
+                    if (J[u].nn) atomicAdd(&Enpos[g * 64 + J[u].i], 2 * J[u].nn);
+                }
+                if (!contiguous) { // (a block boundary inside the trip, or nothing at all)
+                    run_flush(s_q[wl], rq, lane);
+                    run_flush(s_s[wl], rs, lane);
+#pragma unroll
+                    for (uint32_t u = 0; u < SPLIT_ROUNDS; u++) {
+                        if (!(base + u * WAVE < Tq) || !J[u].on) continue;
+                        const uint32_t have = J[u].have, k = J[u].k, out = J[u].out, nb = (have + 3) >> 2;
+                        uint8_t *o = arena + J[u].dst + 4 * k;
+                        if (nb == 4) store_u32_unaligned(o, out);
+                        else {
+                            if (nb & 2) { uint16_t v = (uint16_t)out; __builtin_memcpy(o, &v, 2); }
+                            if (nb & 1) o[nb & 2] = (uint8_t)(out >> (8 * (nb & 2)));
+                        }
+                        store_piece(arena + J[u].dstq + 16 * k, J[u].y, have);
+                    }
+                } else {
+                    // quality bytes
+                    if (rq.n && rq.a0 + rq.n != q_first) run_flush(s_q[wl], rq, lane);
+                    uint32_t head = 0;
+                    if (!rq.n) { rq.a0 = q_first & ~15u; head = q_first & 15u; }
+                    const uint32_t pos0 = rq.n ? rq.n : head;
+#pragma unroll
+                    for (uint32_t u = 0; u < SPLIT_ROUNDS; u++)
+                        if (base + u * WAVE < Tq && J[u].on) store_piece(s_q[wl] + pos0 + (J[u].dstq + 16 * J[u].k - q_first), J[u].y, J[u].have);
+                    run_store(s_q[wl], rq, pos0 + totq, head, lane);
+                    // packed bases
+                    if (rs.n && rs.a0 + rs.n != s_first) run_flush(s_s[wl], rs, lane);
+                    uint32_t shead = 0;
+                    if (!rs.n) { rs.a0 = s_first & ~15u; shead = s_first & 15u; }
+                    const uint32_t spos0 = rs.n ? rs.n : shead;
+#pragma unroll
+                    for (uint32_t u = 0; u < SPLIT_ROUNDS; u++) {
+                        if (!(base + u * WAVE < Tq) || !J[u].on) continue;
+                        const uint32_t nb = (J[u].have + 3) >> 2, out = J[u].out;
+                        uint8_t *o = s_s[wl] + spos0 + (J[u].dst + 4 * J[u].k - s_first);
+                        if (nb == 4) store_u32_unaligned(o, out);
+                        else {
+                            if (nb & 2) { uint16_t v = (uint16_t)out; __builtin_memcpy(o, &v, 2); }
+                            if (nb & 1) o[nb & 2] = (uint8_t)(out >> (8 * (nb & 2)));
+                        }
+                    }
+                    run_store(s_s[wl], rs, spos0 + tots, shead, lane);
+                }
+            }
+#else
 #pragma unroll
             for (uint32_t u = 0; u < SPLIT_ROUNDS; u++)
                 if (base + u * WAVE < Tq) commit(J[u]);
+#endif
         }
+#if SPLIT_STAGE
+        run_flush(s_q[wl], rq, lane); // the wave's next 64 records lie elsewhere
+        run_flush(s_s[wl], rs, lane);
+#endif
         // ---- header and plus payloads (without '@' / '+'), after their u16 length
         for (uint32_t base = 0; base < Th; base += WAVE) {
             const uint32_t p = base + lane;
@@ -771,17 +894,42 @@ __global__ __launch_bounds__(256) void k_split(const uint8_t *__restrict__ text,
             piece_locate(pm_ih, ih, ph, on ? p : 0, &i, &k);
             const uint32_t Hi = (uint32_t)__shfl((int)H, (int)i, WAVE), src = (uint32_t)__shfl((int)s_hdr, (int)i, WAVE);
             const uint32_t dst = (uint32_t)__shfl((int)d_hdr, (int)i, WAVE);
+            uint32_t x[4] = {0, 0, 0, 0};
+            const uint32_t nbh = on ? (Hi + 2 - 16 * k < 16 ? Hi + 2 - 16 * k : 16) : 0u;
             if (on) { // piece k = bytes [16 k, 16 k + 16) of the record's image [u16 H][H payload bytes]
-                uint32_t x[4];
                 if (k) load_piece(text, src + 16 * k - 2, n_text, x);
                 else {
                     uint32_t y[4];
                     load_piece(text, src, n_text, y);
                     x[0] = (y[0] << 16) | (Hi & 0xFFFFu); x[1] = (y[1] << 16) | (y[0] >> 16); x[2] = (y[2] << 16) | (y[1] >> 16); x[3] = (y[3] << 16) | (y[2] >> 16);
                 }
-                store_piece(arena + dst + 16 * k, x, Hi + 2 - 16 * k < 16 ? Hi + 2 - 16 * k : 16);
             }
+#if SPLIT_STAGE
+            { // the round's pieces are one run of the headers stream (unless a block ends inside): through the stage, as above
+                const unsigned long long act = __ballot(on);
+                const int l0 = __ffsll((long long)act) - 1, l1 = 63 - __clzll((long long)act);
+                const uint32_t ah = dst + 16 * k;
+                const uint32_t toth = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(nbh), 63);
+                const uint32_t h_first = (uint32_t)__builtin_amdgcn_readlane((int)ah, l0), h_last = (uint32_t)__builtin_amdgcn_readlane((int)(ah + nbh), l1);
+                if (h_last - h_first == toth) {
+                    if (rq.n && rq.a0 + rq.n != h_first) run_flush(s_q[wl], rq, lane);
+                    uint32_t head = 0;
+                    if (!rq.n) { rq.a0 = h_first & ~15u; head = h_first & 15u; }
+                    const uint32_t pos0 = rq.n ? rq.n : head;
+                    if (on) store_piece(s_q[wl] + pos0 + (ah - h_first), x, nbh);
+                    run_store(s_q[wl], rq, pos0 + toth, head, lane);
+                } else {
+                    run_flush(s_q[wl], rq, lane);
+                    if (on) store_piece(arena + ah, x, nbh);
+                }
+            }
+#else
+            if (on) store_piece(arena + dst + 16 * k, x, nbh);
+#endif
         }
+#if SPLIT_STAGE
+        run_flush(s_q[wl], rq, lane);
+#endif
         for (uint32_t base = 0; base < Tp; base += WAVE) {
             const uint32_t p = base + lane;
             const bool on = p < Tp;

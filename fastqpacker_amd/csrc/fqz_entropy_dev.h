@@ -377,6 +377,7 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
     //      off its dominant byte: the candidate is the first byte the wave sees, matches are counted with SWAR compares
     //      in registers and added once per wave.
     S.ctab[t] = 0;
+    __syncthreads(); // (the first chunk's counts must not arrive before every bin is cleared: full chunks are loaded without a barrier)
     uint32_t same_mask = 0; // bit k: chunk k is one repeated byte
     if (HDR) { // the histograms come with the literals: no pass over them here
         uint32_t c = 0;
@@ -406,7 +407,15 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
         const uint32_t mk = M - k * FQZ_CHUNK < FQZ_CHUNK ? M - k * FQZ_CHUNK : FQZ_CHUNK;
         const uint8_t *csrc = HDR ? H->lit[k] : src + (size_t)k * FQZ_CHUNK;
         ChunkSyms C;
-        load_chunk_syms(S, csrc, HDR ? H->n_lit[k] : mk, C);
+        if (!HDR && mk == FQZ_CHUNK) {
+            // a full chunk: the histogram does not care which lane holds which bytes, so the loads are the coalesced kind (a wave
+            // reads 1 KiB in a row) and need no barrier; the layout the coder wants (64 consecutive bytes a lane) is loaded in phase 2
+            const uint4 *p4 = (const uint4 *)csrc;
+            const uint4 a = p4[t], b = p4[t + 256], c = p4[t + 512], d = p4[t + 768];
+            C.sym[0] = a.x; C.sym[1] = a.y; C.sym[2] = a.z; C.sym[3] = a.w; C.sym[4] = b.x; C.sym[5] = b.y; C.sym[6] = b.z; C.sym[7] = b.w;
+            C.sym[8] = c.x; C.sym[9] = c.y; C.sym[10] = c.z; C.sym[11] = c.w; C.sym[12] = d.x; C.sym[13] = d.y; C.sym[14] = d.z; C.sym[15] = d.w;
+            C.cnt = 64; C.nstreams = 4;
+        } else load_chunk_syms(S, csrc, HDR ? H->n_lit[k] : mk, C);
         const uint32_t b0 = (uint32_t)csrc[0] * 0x01010101u;
         const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(C.sym[0] & 0xFF)); // wave-uniform candidate byte
         const uint32_t cand4 = cand * 0x01010101u;
@@ -424,7 +433,7 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
                 atomicAdd(&S.ctab[(C.sym[d] >> (bit - 7)) & 0xFF], 1u);
             }
         }
-        n_cand = wave_sum(n_cand);
+        n_cand = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(n_cand), 63); // (DPP: no trip through the LDS crossbar)
         if (lane == 0 && n_cand) atomicAdd(&S.ctab[cand], n_cand);
         if (!__syncthreads_or(differs != 0) && !(HDR && H->nseq[k])) same_mask |= 1u << k;
     }

@@ -8,8 +8,8 @@ cd $R
 rocprofv3 -L > $OUT/counters_list.txt 2>&1 || true
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_WAVES SQ_WAIT_INST_LDS"
-rocprofv3 --pmc $P1 --output-format csv -d $OUT/p1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-v3 --decode-steps 1 --profile 0 --inflight 0 > $OUT/p1.log 2>&1 || true
-rocprofv3 --pmc $P2 --output-format csv -d $OUT/p2 -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-v3 --decode-steps 1 --profile 0 --inflight 0 > $OUT/p2.log 2>&1 || true
+rocprofv3 --pmc $P1 --output-format csv -d $OUT/p1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-v3 --no-supp --decode-steps 1 --profile 0 --inflight 0 > $OUT/p1.log 2>&1 || true
+rocprofv3 --pmc $P2 --output-format csv -d $OUT/p2 -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-v3 --no-supp --decode-steps 1 --profile 0 --inflight 0 > $OUT/p2.log 2>&1 || true
 python3 - <<'PY'
 import csv, glob, os, collections
 out = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/pmc_sq"

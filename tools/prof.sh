@@ -6,11 +6,11 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu --no-v3 --decode-steps 1 --inflight 0 > $OUT/bench_trace.log 2>&1 || true
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu --decode-steps 0 --profile 0 --inflight 0 --no-v3 > $OUT/bench_fetch.log 2>&1 || true
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu --decode-steps 0 --profile 0 --inflight 0 --no-v3 > $OUT/bench_write.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu --no-v3 --no-supp --decode-steps 1 --inflight 0 > $OUT/bench_trace.log 2>&1 || true
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu --decode-steps 0 --profile 0 --inflight 0 --no-v3 --no-supp > $OUT/bench_fetch.log 2>&1 || true
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu --decode-steps 0 --profile 0 --inflight 0 --no-v3 --no-supp > $OUT/bench_write.log 2>&1 || true
 # the same batch as a version-3 container (FQZ-R1): kernel trace only
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_v3 -- python3 bench.py --steps 5 --warmup 1 --no-cpu --container 3 --decode-steps 1 --inflight 0 > $OUT/bench_trace_v3.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_v3 -- python3 bench.py --steps 5 --warmup 1 --no-cpu --no-supp --container 3 --decode-steps 1 --inflight 0 > $OUT/bench_trace_v3.log 2>&1 || true
 find $OUT -name "*.csv" | head -20
 python3 - <<'PY'
 import csv, glob, os, collections
