@@ -11,6 +11,7 @@ ENCODING_PHRED64 = 1
 DETECT_ENCODING = -1
 BATCH_FINAL = 1
 BATCH_V3 = 2
+BATCH_HALVES = 8  # experimental: two halves of a large batch in flight (include/fqz.h)
 BATCH_SEG = 4  # experimental FQZ-S1 segment framing (include/fqz.h)
 DEFAULT_BLOCK_SIZE = 100000
 STREAM_NAMES = ["seq", "qual", "headers", "plus", "npos", "lengths"]

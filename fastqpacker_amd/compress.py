@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import (lib, check, default_ctx, BatchResult, Options, DecompressOptions, FqzError, DEFAULT_BLOCK_SIZE,
-                   DETECT_ENCODING, BATCH_FINAL, BATCH_V3, BATCH_SEG, SynthParams)
+                   DETECT_ENCODING, BATCH_FINAL, BATCH_V3, BATCH_SEG, BATCH_HALVES, SynthParams)
 
 DefaultBlockSize = DEFAULT_BLOCK_SIZE  # compress.go:71
 

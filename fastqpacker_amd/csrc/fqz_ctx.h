@@ -54,7 +54,20 @@ struct PinnedBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
+// extras of a launch that is one half of a batch encoded as two halves in flight (fqz_api.hip: encode_batch_halves)
+struct EncLaunchExtra {
+    uint32_t skip = 0;                 // the text proper starts at d_text[skip] (< 16)
+    int phase = 0;                     // 0 whole launch, 1 front end only, 2 the rest (enc_launch_groups)
+    bool want_front = false;           // copy the counters to h_front behind the front end (line index, record table, plan) and record ev_front
+    bool want_layout_event = false;    // record ev_layout behind k_layout
+    const EncInfo *prev_info = nullptr; // device: the launch whose blocks lie in front of this one's in d_out
+    hipEvent_t prev_layout = nullptr;  // ... and the event behind its k_layout
+};
+
 struct EncState {
+    EncLaunchExtra extra;
+    PinnedBuf h_front;
+    hipEvent_t ev_front = nullptr, ev_layout = nullptr;
     // inputs of the batch in flight
     const uint8_t *d_text = nullptr;
     size_t n_bytes = 0;
@@ -192,11 +205,16 @@ struct fqz_ctx {
     DevBuf sl_new[3];             // slices in flight of the streaming pipeline: device side,
     PinnedBuf sl_hin[3], sl_hout[3]; // pinned staging for callback sources / sinks
     std::vector<fqz_ctx *> lanes; // child contexts of the streaming pipeline (fqz_stream.hip): own stream and workspaces each
+    fqz_ctx *half[2] = {nullptr, nullptr}; // child contexts of fqz_encode_batch_dev's two halves in flight (fqz_api.hip)
+    hipEvent_t ev_half = nullptr;
+    bool half_off = false;        // a batch of this context had to be redone in one piece: later ones go there directly
 };
 
 // fqz_encode.hip
 int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags,
                    uint8_t *d_out, size_t out_cap, hipStream_t stream);
+int fqz_enc_launch_ex(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags,
+                      uint8_t *d_out, size_t out_cap, hipStream_t stream, const EncLaunchExtra *x);
 int fqz_enc_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block_off, uint64_t *block_len, size_t max_blocks);
 int fqz_enc_get_streams(fqz_ctx *ctx, uint32_t block, uint8_t *streams[6], size_t stream_len[6]);
 int fqz_enc_get_stamps(fqz_ctx *ctx, unsigned long long *out, size_t max_chunks, size_t *n_chunks);

@@ -241,9 +241,11 @@ __global__ __launch_bounds__(256) void k_line_starts(const uint8_t *__restrict__
 // reads - is turned into (line start, flags) entries by consecutive lanes: dense stores, and the bytes either side of
 // the newline are two L1-hot byte loads.
 #define LL_CAP 512u
+// skip (< 16): the text proper starts at text[skip] - a batch that begins inside a 16-byte unit (the second half of a batch cut
+// at a block boundary, fqz_encode_batch_dev): line 0 starts there and newlines in front of it do not count
 __global__ __launch_bounds__(256) void k_line_local(const uint8_t *__restrict__ text, uint32_t n, uint32_t n_tiles, uint32_t *__restrict__ ls,
                                                     uint8_t *__restrict__ lf, uint32_t *__restrict__ lsl, uint8_t *__restrict__ lfl,
-                                                    uint32_t *__restrict__ tile_cnt, EncInfo *info)
+                                                    uint32_t *__restrict__ tile_cnt, EncInfo *info, uint32_t skip)
 {
     __shared__ uint16_t s_pos[4][LL_CAP];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -259,11 +261,13 @@ __global__ __launch_bounds__(256) void k_line_local(const uint8_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; k++) // 0x80 per matching byte -> 4 bits (the multiply gathers bits 7, 15, 23, 31 at bits 21..24)
             m[q] |= ((((zero_bytes(w[k] ^ 0x0A0A0A0Au) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * k);
-        c[q] = __popc(m[q]);
         if (tile == 0 && q == 0 && lane == 0) {
-            ls[0] = 0;
-            lf[0] = (uint8_t)(n ? (((v.x & 0xFF) == '@' ? 1 : (v.x & 0xFF) == '+' ? 2 : 0) << 1) : 0);
+            m[q] &= ~((1u << skip) - 1u);
+            const uint32_t b0 = skip < n ? (uint32_t)text[skip] : 0u;
+            ls[0] = skip;
+            lf[0] = (uint8_t)(n > skip ? ((b0 == '@' ? 1 : b0 == '+' ? 2 : 0) << 1) : 0);
         }
+        c[q] = __popc(m[q]);
     }
     // exclusive prefix of the counts in text order (row-major), packed 2 x 16 bits (a row holds <= 1024 newlines)
     const uint32_t lo = c[0] | (c[1] << 16), hi = c[2] | (c[3] << 16);
@@ -1233,7 +1237,9 @@ __device__ __forceinline__ void put_le32(uint8_t *p, uint32_t v) { p[0] = (uint8
 
 // csize has been scanned in place (exclusive prefix, total at [n_chunks])
 // one 256-thread workgroup, one thread per block: block size = 36 + its six frames, offsets by a workgroup scan
-__global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap, uint32_t hcap)
+// prev (nullptr: none): the counters of the launch whose blocks lie in front of this one's in `out` (the first half of a batch that is
+// encoded as two halves in flight): this launch's blocks start behind them
+__global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap, uint32_t hcap, const EncInfo *prev)
 {
     __shared__ uint32_t sh[4];
     if (blockIdx.x) return;
@@ -1245,7 +1251,8 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
     if (t == 0 && info->n_hchunks > hcap && info->status == 0) info->status = FQZ_E_TOO_LARGE; // headers side buffers too small: the host relaunches
     __syncthreads();
     const uint32_t n_blocks = info->status ? 0u : info->n_blocks;
-    unsigned long long carry = 0; // bytes of the blocks of earlier strips
+    const unsigned long long out_base = prev ? (prev->status ? 0ull : prev->out_len) : 0ull;
+    unsigned long long carry = out_base; // bytes of the blocks in front: of earlier strips, and of the launch in front of this one
     unsigned long long comp[FQZ_NS] = {0, 0, 0, 0, 0, 0};
     for (uint32_t base = 0; base < n_blocks; base += 256) {
         const uint32_t b = base + t;
@@ -1280,7 +1287,7 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
     for (int s = 0; s < FQZ_NS; s++) if (comp[s]) atomicAdd(&info->stream_comp[s], comp[s]);
     const unsigned long long total = carry; // identical in every thread
     if (t == 0) {
-        info->out_len = total;
+        info->out_len = total - out_base;
         if ((total > out_cap || total > 0xFFFFFFF0ull) && !info->status) info->status = FQZ_E_DST_SMALL;
     }
     if (total > out_cap || total > 0xFFFFFFF0ull || info->status) return;
@@ -1547,8 +1554,16 @@ static int enc_launch_seg(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, u
 int fqz_enc_launch(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags, uint8_t *d_out,
                    size_t out_cap, hipStream_t st)
 {
+    return fqz_enc_launch_ex(ctx, d_text, n_bytes, rpb, qual_encoding, flags, d_out, out_cap, st, nullptr);
+}
+
+// x (nullptr: a plain launch): the extras of a batch that is encoded as two halves in flight (fqz_api.hip: encode_batch_halves)
+int fqz_enc_launch_ex(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint32_t rpb, int qual_encoding, uint32_t flags, uint8_t *d_out,
+                      size_t out_cap, hipStream_t st, const EncLaunchExtra *x)
+{
     EncState &e = ctx->enc;
     if (e.in_flight) return FQZ_E_ARG;
+    e.extra = x ? *x : EncLaunchExtra();
     if (!rpb) rpb = FQZ_DEFAULT_BLOCK_SIZE;
     // FQZ-S1 (fqz_seg.h) is opt-in: FQZ_BATCH_SEG in `flags`, or FQZ_ENC_SEG=1 in the environment for every entry point (oracle:
     // fqzo_options.framing = 1); container version 3 has no segment form
@@ -1617,6 +1632,12 @@ static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes
     const uint32_t rs_tiles = e.rec_cap / RS_TILE + 1, zwords = zt_tiles + zt_npos + zt_chunks + 4 * rs_tiles + 1;
     if ((rc = e.zstate.ensure(8ull * zwords))) return rc;
     unsigned long long *z_tiles = e.zstate.as<unsigned long long>(), *z_npos = z_tiles + zt_tiles, *z_chunks = z_npos + zt_npos, *rs_state = z_chunks + zt_chunks;
+    // phase: 0 = the whole launch; 1 = the front end only (line index, record table, plan, counters to the host); 2 = the rest of
+    // a launch whose front end is in the stream already (same arguments).  The two halves of a batch (fqz_api.hip) interleave
+    // theirs, so that the second half's front end is queued before the first half's long tail of launches.
+    const int phase = e.extra.phase;
+    if (phase != 2) {
+    if (e.extra.skip && e.two_pass_left > 0) return FQZ_E_TOO_LARGE; // (the two-pass index knows no skip: the caller encodes the batch in one piece)
     hipLaunchKernelGGL(k_init, dim3((zwords + 255) / 256 < 64 ? (zwords + 255) / 256 : 64), dim3(256), 0, st, info, qual_encoding, z_tiles, zwords);
     const bool two_pass = e.two_pass_left > 0; // (the text of the last batches had lines too short for the single-pass index)
     if (two_pass) e.two_pass_left--;
@@ -1625,7 +1646,7 @@ static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes
         // the tile-local line tables borrow the chunk slots, which nothing uses before k_entropy
         uint32_t *lsl = (uint32_t *)slots;
         uint8_t *lfl = slots + 4ull * e.n_tiles * LL_CAP;
-        PROF(ctx, st, "k_line_local", hipLaunchKernelGGL(k_line_local, dim3((e.n_tiles + 3) / 4), dim3(256), 0, st, d_text, n, e.n_tiles, ls, lf, lsl, lfl, tile, info));
+        PROF(ctx, st, "k_line_local", hipLaunchKernelGGL(k_line_local, dim3((e.n_tiles + 3) / 4), dim3(256), 0, st, d_text, n, e.n_tiles, ls, lf, lsl, lfl, tile, info, e.extra.skip));
         if ((rc = launch_scan(ctx, "scan_tiles", st, tile, nullptr, e.n_tiles, e.n_tiles, z_tiles))) return rc;
         PROF(ctx, st, "k_line_gather", hipLaunchKernelGGL(k_line_gather, dim3((e.n_tiles + LG_TILES - 1) / LG_TILES), dim3(256), 0, st, tile, e.n_tiles, lsl, lfl, ls, lf, e.line_cap));
     } else if (e.n_tiles) {
@@ -1648,6 +1669,15 @@ static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes
         hipLaunchKernelGGL(k_finish_detect, dim3(1), dim3(64), 0, st, info);
     }
     PROF(ctx, st, "k_plan1", hipLaunchKernelGGL(k_plan1, dim3(1), dim3(256), 0, st, info, E, estride, plans, rpb, e.arena_cap, (uint32_t)main_cap));
+    if (e.extra.want_front) { // the caller waits for the counters of the front end (what was consumed, the encoding detected, errors)
+        if ((rc = e.h_front.ensure(sizeof(EncInfo)))) return rc;
+        if (!e.ev_front) { HIP_TRY(hipEventCreateWithFlags(&e.ev_front, hipEventDisableTiming)); }
+        HIP_TRY(hipMemcpyAsync(e.h_front.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(e.ev_front, st));
+    }
+    HIP_TRY(hipGetLastError());
+    if (phase == 1) return FQZ_OK;
+    } // phase != 2
     const uint32_t group_cap = e.chunk_cap / FQZ_GROUP + FQZ_NS * e.block_cap + 8;
     if ((rc = e.gmap.ensure(48ull * group_cap))) return rc; // gmap | hmap | rmap
     if ((rc = e.xmap.ensure(16ull * group_cap + 4ull * (e.chunk_cap + 8)))) return rc;
@@ -1728,7 +1758,12 @@ static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes
     HIP_TRY(hipStreamWaitEvent(st, e.ev_join3, 0));
     PROF(ctx, st, "k_hdr_patch", hipLaunchKernelGGL(k_hdr_patch, dim3(hcap), dim3(64), 0, st, info, hlist, hcap, hside, hsec, slots, csize));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
-    PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap, hcap));
+    if (e.extra.prev_layout) HIP_TRY(hipStreamWaitEvent(st, e.extra.prev_layout, 0)); // (the half in front knows its size)
+    PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap, hcap, e.extra.prev_info));
+    if (e.extra.want_layout_event) {
+        if (!e.ev_layout) { HIP_TRY(hipEventCreateWithFlags(&e.ev_layout, hipEventDisableTiming)); }
+        HIP_TRY(hipEventRecord(e.ev_layout, st));
+    }
     if (rpb > 64) { // (blocks of <= 64 records carry no samples)
         const uint32_t xper = (rpb / 64 + 255) / 256;
         PROF(ctx, st, "k_samples", hipLaunchKernelGGL(k_samples, dim3(xper * e.block_cap * 3), dim3(256), 0, st, info, plans, E, estride, d_out, xper));
@@ -1943,7 +1978,7 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
     PROF(ctx, st, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, st, info, e.xmap.as<uint4>(), d_src, d_src, xsum));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_dst, cap, 0u);
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_dst, cap, 0u, (const EncInfo *)nullptr);
     PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks ? chunks : 1), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, csize + chunks + 2, xsum, d_src, d_dst, (uint32_t)S_SEQ));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));

@@ -154,6 +154,8 @@ typedef struct {
 #define FQZ_BATCH_V3 2u           /* write FQZ_VERSION3 blocks: the quality stream in rANS blocks (the caller writes version 3 into the file header) */
 #define FQZ_BATCH_SEG 4u          /* experimental: FQZ-S1 segment framing (one zstd frame per 64 KiB of a block's text and stream) for
                                    * every block that qualifies; any zstd decoder reads it, ours at the general path's speed */
+#define FQZ_BATCH_HALVES 8u       /* experimental: a batch of 192 MiB or more runs as two halves in flight on two child contexts (same bytes out;
+                                   * slower than one piece today - the host cannot queue two halves' launches fast enough; experiments/README.md) */
 #define FQZ_BATCH_FINAL 1u        /* last batch of the input: a short last block is emitted, an unterminated tail is dropped (parser.go:210-220) */
 
 /* Encodes records_per_block-record blocks from FASTQ text already in HBM.

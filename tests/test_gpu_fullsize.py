@@ -18,7 +18,7 @@ def fq():
     return fq
 
 
-def _encode_dev(fq, text_np, enc, version=2):
+def _encode_dev(fq, text_np, enc, version=2, extra_flags=0):
     import torch
     from fastqpacker_amd._lib import BatchResult, lib
     dev = torch.device("cuda:0")
@@ -29,7 +29,7 @@ def _encode_dev(fq, text_np, enc, version=2):
     nb = text_np.size // 200 // fq.DEFAULT_BLOCK_SIZE + 8
     offs, lens = (C.c_uint64 * nb)(), (C.c_uint64 * nb)()
     fq._lib.check(lib().fqz_encode_batch_dev(ctx.handle, d_text.data_ptr(), text_np.size, fq.DEFAULT_BLOCK_SIZE, enc,
-                                             fq.BATCH_FINAL | (fq.BATCH_V3 if version == 3 else 0),
+                                             fq.BATCH_FINAL | (fq.BATCH_V3 if version == 3 else 0) | extra_flags,
                                              d_out.data_ptr(), d_out.numel(), C.byref(res), offs, lens, nb, None))
     body = d_out[: int(res.out_len)].cpu().numpy()
     # and back on the device
@@ -60,6 +60,10 @@ def test_default_bench_batch_is_byte_identical_to_the_oracle(fq):
     assert want[9] == 0                                                   # Phred+33 detected by the oracle too
     assert body.size + 10 == want.size and np.array_equal(body, want[10:]), _first_diff(body, want[10:])
     assert sum(lens) == body.size
+    # the same batch as two halves in flight (FQZ_BATCH_HALVES: the second half starts at the block boundary the first one reports)
+    body_h, res_h, lens_h, back_h = _encode_dev(fq, text, fq.ENCODING_PHRED33, extra_flags=fq.BATCH_HALVES)
+    assert back_h and res_h.n_blocks == 29 and res_h.n_records == res.n_records and lens_h == lens and np.array_equal(body_h, body)
+    assert list(res_h.stream_raw) == list(res.stream_raw) and list(res_h.stream_comp) == list(res.stream_comp)
     # the same batch as a version-3 container (FQZ-R1: rANS-coded qualities)
     body3, res3, lens3, back3 = _encode_dev(fq, text, fq.ENCODING_PHRED33, version=3)
     want3 = np.frombuffer(O.compress(text, workers=16, entropy=2), dtype=np.uint8)
