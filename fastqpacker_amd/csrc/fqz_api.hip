@@ -193,19 +193,20 @@ extern "C" int fqz_read_block_header(const uint8_t *in, size_t n, uint8_t versio
 extern "C" size_t fqz_entropy_bound(size_t n)
 {
     if (!n) return 0;
-    // FQZ-H2 payload: index frame (24 + 3 per zstd block), per 64 KiB group a frame header and a checksum, per block a header
+    // FQZ-H2 payload: index frame (24 + per zstd block its size, 3 bytes, and its entry points), per 64 KiB group a frame header and
+    // a checksum, per block a header
     const size_t chunks = (n + FQZ_CHUNK - 1) / FQZ_CHUNK, groups = (chunks + FQZ_GROUP - 1) / FQZ_GROUP;
-    return 24 + 3 * chunks + 11 * groups + n + 3 * chunks;
+    return 24 + (3 + 2 * FQZ_ENT) * chunks + 11 * groups + n + 3 * chunks;
 }
 
 extern "C" size_t fqz_encode_bound_blocks(size_t n_bytes, uint32_t rpb)
 {
     // pre-entropy bytes <= 2*text + small per-record terms (each record has >= 6 text bytes), every chunk stored raw,
-    // per zstd block 6 bytes (header + index entry), per 64 KiB group 11; per block of records a 36-byte header and six
+    // per zstd block 6 + 24 bytes (header + index entry + entry points), per 64 KiB group 11; per block of records a 36-byte header and six
     // payloads with a 24-byte index, a short last group and a short last chunk each
     if (!rpb) rpb = FQZ_DEFAULT_BLOCK_SIZE;
     const size_t blocks = n_bytes / 6 / rpb + 2;
-    return 2 * n_bytes + (n_bytes / 1024 + 64) * 128 + blocks * (36 + 6 * (24 + 11 + 6) + 3 * 4) + n_bytes / 32 /* record samples: 12 bytes per 64 records */ + 4096;
+    return 2 * n_bytes + (n_bytes / 1024 + 64) * 128 + blocks * (36 + 6 * (24 + 11 + 6 + 2 * FQZ_ENT) + 3 * 4) + n_bytes / 32 /* record samples: 12 bytes per 64 records */ + 4096;
 }
 extern "C" size_t fqz_encode_bound(size_t n_bytes) { return fqz_encode_bound_blocks(n_bytes, FQZ_DEFAULT_BLOCK_SIZE); }
 

@@ -34,6 +34,7 @@ struct DecBlock {
     uint32_t n_frames[FQZ_NS];      // zstd frames of the payload (content checksums are verified per frame)
     uint32_t frame_base[FQZ_NS];    // first entry of the payload in the frame table
     uint32_t samp_off[FQZ_NS];      // offset in d_in of the record samples of the payload's index (stream offsets of records 64, 128, ...); 0: none
+    uint32_t ent_off[FQZ_NS];       // offset in d_in of the entry points of the payload's index (FQZ_ENT u16 a zstd block); 0: none
     uint32_t seq_scratch;           // arena offset of the scratch of the headers stream's blocks with sequences (DSEQ_STRIDE each; 0: none)
     uint32_t seq_scratch_len;       // the same for the lengths stream (a chunk of equal read lengths is one match)
 };
@@ -57,6 +58,7 @@ struct DecChunk {
     uint32_t seq_len;   // 0, or the bytes of the block's Sequences_Section (fqz_decode_seq.h): dst_off / regen then describe the
     uint32_t out_off;   // LITERALS (decoded into a scratch area) and out_off / out_len the block's place in the stream
     uint32_t out_len;
+    uint32_t ent_off;   // 0, or the offset in d_in of the block's entry points (FQZI index: three per Huffman stream)
 };
 
 #define DSEQ_MAX 2048u                                   // sequences per block the fast path takes
@@ -146,14 +148,15 @@ __device__ __forceinline__ bool skippable_magic(const uint8_t *p) { return (p[0]
 #define H2_IDX_HDR 24u
 // flags bit 0: behind the block sizes, [records u32][stream offset u32 of records 64, 128, ...] (*samples = offset of the first
 // one inside the payload, *srec = the record count it was made for)
-__device__ __forceinline__ bool h2_index(const uint8_t *p, uint32_t n, uint32_t *raw, uint32_t *nch, uint32_t *samples, uint32_t *srec)
+// flags bit 1: behind those, FQZ_ENT u16 a block: where a decoder may enter the block's Huffman streams (*ent = offset inside the payload)
+__device__ __forceinline__ bool h2_index(const uint8_t *p, uint32_t n, uint32_t *raw, uint32_t *nch, uint32_t *samples, uint32_t *srec, uint32_t *ent)
 {
     if (n < H2_IDX_HDR || !skippable_magic(p) || p[0] != 0x50) return false;
     if (!(p[8] == 'F' && p[9] == 'Q' && p[10] == 'Z' && p[11] == 'I' && p[12] == 1)) return false;
     const uint32_t sz = rd32(p + 4), r = rd32(p + 16), c = rd32(p + 20), flags = p[14] | ((uint32_t)p[15] << 8);
-    if (r == 0 || r > 0x7FFFFFF0u || c != (r + FQZ_CHUNK - 1) / FQZ_CHUNK || (flags & ~1u)) return false;
+    if (r == 0 || r > 0x7FFFFFF0u || c != (r + FQZ_CHUNK - 1) / FQZ_CHUNK || (flags & ~3u)) return false;
     unsigned long long want = H2_IDX_HDR - 8 + 3ull * c;
-    *samples = 0; *srec = 0;
+    *samples = 0; *srec = 0; *ent = 0;
     if (flags & 1) {
         if (8ull + want + 4 > n) return false;
         const uint32_t nr = rd32(p + H2_IDX_HDR + 3 * c);
@@ -161,6 +164,11 @@ __device__ __forceinline__ bool h2_index(const uint8_t *p, uint32_t n, uint32_t 
         want += 4 + 4ull * ((nr - 1) / 64);
         *samples = H2_IDX_HDR + 3 * c + 4;
         *srec = nr;
+    }
+    if (flags & 2) {
+        if (want + 8ull > 0x7FFFFFF0ull) return false;
+        *ent = (uint32_t)(want + 8);
+        want += 2ull * FQZ_ENT * c;
     }
     if (sz != want || 8ull + sz > n) return false;
     *raw = r;
@@ -202,14 +210,16 @@ __global__ __launch_bounds__(64) void k_dec_fhdr(const uint8_t *in, DecInfo *inf
     const uint32_t n = b->pay_len[s];
     b->indexed[s] = 0;
     b->samp_off[s] = 0;
+    b->ent_off[s] = 0;
     if (!n) { b->raw_len[s] = 0; b->n_chunks[s] = 0; b->n_frames[s] = 0; return; }
-    uint32_t raw, nch, samples, srec;
-    if (h2_index(in + b->pay_off[s], n, &raw, &nch, &samples, &srec)) { // our own payload: sizes and block places come from its index (k_dec_index)
+    uint32_t raw, nch, samples, srec, ent;
+    if (h2_index(in + b->pay_off[s], n, &raw, &nch, &samples, &srec, &ent)) { // our own payload: sizes and block places come from its index (k_dec_index)
         b->raw_len[s] = raw;
         b->n_chunks[s] = nch;
         b->n_frames[s] = (nch + FQZ_GROUP - 1) / FQZ_GROUP;
         b->indexed[s] = 1;
         if (samples && srec == b->nrec && (s == S_HDR || s == S_PLUS || s == S_NPOS)) b->samp_off[s] = b->pay_off[s] + samples;
+        if (ent) b->ent_off[s] = b->pay_off[s] + ent;
         return;
     }
     uint32_t hdr;
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                         c.tree_off = (type == 2 && lt2 == 3) ? tree_off : 0;
                         c.tree_len = (type == 2 && lt2 == 3) ? tree_len : 0;
                         c.stream = (uint32_t)s;
-                        c.seq_len = 0; c.out_off = dst; c.out_len = regen;
+                        c.seq_len = 0; c.out_off = dst; c.out_len = regen; c.ent_off = 0;
                         out[nch] = c;
                     }
                     dst += regen;
@@ -726,6 +736,7 @@ __global__ __launch_bounds__(256) void k_dec_index(const uint8_t *in, DecInfo *i
                 d.src_off = pos + 3; d.csize = csize; d.dst_off = b->a_off[s] + c * FQZ_CHUNK; d.regen = mk; d.btype = type;
                 d.tree_off = 0; d.tree_len = 0; d.stream = (uint32_t)s;
                 d.seq_len = 0; d.out_off = d.dst_off; d.out_len = mk;
+                d.ent_off = (type == 2 && b->ent_off[s]) ? b->ent_off[s] + 2u * FQZ_ENT * c : 0u;
                 if (3 + csize != sz || last != (last_in_group ? 1u : 0u)) bad = true;
                 else if (type == 3) {
                     // FQZ-R1 (version-3 files, fqz_rans.h): m u16 | tflag | [table] | words | 16 states.  The first such block of a
@@ -881,7 +892,7 @@ __device__ __forceinline__ int bbp_init(BackBitsP &b, const uint8_t *p, uint32_t
 #define FQZ_RANS_DECODER
 #include "fqz_rans.h"
 
-#define HG 16           // blocks per wave
+#define HG 16           // blocks per wave, four lanes a block (one per Huffman stream)
 #define L1_BITS 8
 #define L1_ESC 0xFFFFu
 struct HufGroupLds {
@@ -893,13 +904,23 @@ struct HufGroupLds {
 
 // (the launch covers the chunks [first, first + count): the host numbers the chunks of the quality streams first, so that the
 //  launch for them and the launch for the other streams are both dense)
+//
+// QL = 4: SIXTEEN lanes a block, four per Huffman stream.  A Huffman stream is one dependent chain - table lookup, shift, next
+// symbol - of up to 4096 steps, and a batch of 1 GB has 35 k blocks of them: 140 k lanes on a chip that wants half a million,
+// each waiting out every LDS and memory latency alone (k_dec_huf ran at 0.9 waves per SIMD and its duration was that of ONE
+// stream, ~0.8 ms).  The FQZI index of our own files therefore carries three ENTRY POINTS per stream (oracle: encode_group_chunks):
+// quarter q of a stream starts at bit E_q with symbol e_q and must end exactly at E_q+1 - the index is a hint, never trusted: a
+// quarter that does not end where the next one began sends the batch to the general path, which reads every stream from its end
+// mark as any zstd decoder does.  A block without entry points (QL = 1 launches; a foreign frame) is decoded by its first quarter.
+template <int QL>
 __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info, DecChunk *chunks, uint8_t *arena, int dbg, uint32_t stream_mask,
                                                 uint32_t first, uint32_t count)
 {
-    __shared__ HufGroupLds G[HG];
+    constexpr uint32_t LPB = 4 * QL, HGQ = 64 / LPB; // lanes per block, blocks per wave
+    __shared__ HufGroupLds G[HGQ];
     __shared__ uint32_t obuf[16 * 64]; // per-lane 64-byte output staging, transposed: dword j of lane l at [j*64 + l]
-    const uint32_t lane = threadIdx.x, grp = lane >> 2, sub = lane & 3;
-    const uint32_t id = first + blockIdx.x * HG + grp;
+    const uint32_t lane = threadIdx.x, grp = lane / LPB, li = lane % LPB, sub = li / QL, qt = li % QL;
+    const uint32_t id = first + blockIdx.x * HGQ + grp;
     if (info->status) return;
     const bool have = id < first + count && id < info->n_chunks;
     DecChunk c;
@@ -921,7 +942,7 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
             ok = (lh + lsize + (c.seq_len ? c.seq_len : 1u) == c.csize && (c.seq_len || src[lh + lsize] == 0) && regen >= 4) ? 1u : 0u;
         }
     }
-    if (ok && sub == 0) {
+    if (ok && li == 0) {
         // weights -> g.l1 (as bytes), FSE scratch -> g.syms
         uint8_t *w = (uint8_t *)g.l1;
         const uint8_t *ip = treeless ? in + c.tree_off : src + lh;
@@ -967,16 +988,16 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
         if (treeless) used = 0; // nothing of this block's literals section is a tree
     }
     if (dbg == 2) return; // timing experiment: parse + weights only
-    // broadcast the leader's verdict to its 4 lanes
-    ok = __shfl(ok, (int)(lane & ~3u), WAVE);
-    tl = __shfl(tl, (int)(lane & ~3u), WAVE);
-    used = __shfl(used, (int)(lane & ~3u), WAVE);
+    // broadcast the leader's verdict to the lanes of its block
+    ok = __shfl(ok, (int)(lane - li), WAVE);
+    tl = __shfl(tl, (int)(lane - li), WAVE);
+    used = __shfl(used, (int)(lane - li), WAVE);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    // ---- first-level table: 64 entries per lane.  Entry v8 covers the TL-bit indices [v8 << (TL-8), ...) when TL > 8.
+    // ---- first-level table: 256 / LPB entries per lane.  Entry v8 covers the TL-bit indices [v8 << (TL-8), ...) when TL > 8.
     const uint32_t l1b = tl < L1_BITS ? tl : L1_BITS;
     if (ok) {
-        for (uint32_t e = sub; e < (1u << l1b); e += 4) {
+        for (uint32_t e = li; e < (1u << l1b); e += LPB) {
             uint32_t v = e << (tl - l1b);       // smallest TL-bit index with this prefix
             uint32_t w = 1;
             for (uint32_t x = 2; x <= tl; x++) w += v >= g.rs[x];
@@ -988,7 +1009,7 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    // ---- the four streams of every block, one lane each
+    // ---- the four streams of every block, QL lanes each
     uint32_t fail = 0;
     if (dbg == 1) return; // timing experiment: tables only
     if (ok) {
@@ -1003,19 +1024,37 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                 uint32_t z4 = rem - 6 - z1 - z2 - z3;
                 uint32_t so = 6 + (sub > 0 ? z1 : 0) + (sub > 1 ? z2 : 0) + (sub > 2 ? z3 : 0);
                 uint32_t sn = sub == 0 ? z1 : (sub == 1 ? z2 : (sub == 2 ? z3 : z4));
-                uint32_t cnt = sub < 3 ? seg : regen - 3 * seg;
-                uint8_t *dst = arena + c.dst_off + sub * seg;
+                const uint32_t L = sub < 3 ? seg : regen - 3 * seg; // symbols of the stream
+                // my quarter: symbols [e_lo, e_hi), bits [p_end, p_top) of the stream (LSB-first from its first byte; the
+                // stream is read from the top down)
+                uint32_t e_lo = 0, e_hi = L, p_end = 0;
+                int p_top = -1; // -1: from the end mark
+                if (QL > 1) {
+                    if (c.ent_off) {
+                        const uint32_t per = ((L + 63) / 64 + 3) & ~3u, q16 = 16 * per;
+                        const uint8_t *ep = in + c.ent_off + 2 * (3 * sub);
+                        e_lo = qt * q16 < L ? qt * q16 : L;
+                        e_hi = (qt == QL - 1 || (qt + 1) * q16 > L) ? L : (qt + 1) * q16;
+                        if (qt) p_top = (int)rd16(ep + 2 * (qt - 1));
+                        if (qt < QL - 1) p_end = rd16(ep + 2 * qt);
+                    } else if (qt) e_lo = e_hi = L; // no entry points: the first quarter decodes the stream
+                }
+                uint32_t cnt = e_hi - e_lo;
+                const bool idle = QL > 1 && qt && !c.ent_off;
+                uint8_t *dst = arena + c.dst_off + sub * seg + e_lo;
                 // 128-bit bit buffer (hi:lo, next bits at the MSB end of hi), four symbols per iteration.  The loads that
                 // top the buffer up are issued at the START of an iteration and merged at its END, so their latency
                 // overlaps four symbol decodes and no load is in flight across the loop back-edge (hipcc copies
                 // loop-carried registers there and would wait for them with vmcnt(0) on every step).
                 const uint8_t *sp = ip + so;
-                if (!sn || !sp[sn - 1]) fail = 1;
+                if (idle) {}
+                else if (!sn || !sp[sn - 1]) fail = 1;
+                else if (p_top > (int)(8 * (sn - 1)) + highbit32_d(sp[sn - 1]) || (p_top >= 0 && (uint32_t)p_top < p_end)) fail = 2; // (an entry point outside the stream)
                 else {
-                    const int hb = highbit32_d(sp[sn - 1]);
+                    if (p_top < 0) p_top = (int)(8 * (sn - 1)) + highbit32_d(sp[sn - 1]); // the end mark: the payload's bits lie below it
                     uint32_t b3 = 0, b2 = 0, b1 = 0, b0 = 0; // the bit buffer as four words (b3 on top): a shift is three v_alignbit + one shift
                     int avail = 0;            // valid bits in b3:b2:b1:b0
-                    int byte_pos = (int)sn;   // bytes [0, byte_pos) not fetched yet
+                    int byte_pos = (p_top + 7) >> 3; // bytes [0, byte_pos) not fetched yet
                     // a dword that ends at byte_pos: bytes before the stream belong to the same zstd block, always readable
                     auto fetch = [&](uint32_t &w, int &nb) {
                         const int take = byte_pos < 4 ? byte_pos : 4;
@@ -1043,8 +1082,8 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                         uint32_t w[4]; int nb[4];
                         for (int q = 0; q < 4; q++) fetch(w[q], nb[q]);
                         for (int q = 0; q < 4; q++) merge(w[q], nb[q]);
-                        const int pad = 8 - hb; // end mark and the zero bits above it
-                        shift_bits((uint32_t)pad);
+                        const int pad = 8 * ((p_top + 7) >> 3) - p_top; // what lies above the entry in its byte (the end mark and the zero bits above it)
+                        if (pad) shift_bits((uint32_t)pad);
                         avail -= pad;
                     }
                     const uint32_t sh1 = 32 - l1b, sh2 = 32 - tl;
@@ -1102,15 +1141,15 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                             }
                         }
                     }
-                    // every bit of the stream must have gone into a symbol: all bytes fetched (the refills see to that as the
-                    // buffer drains) and the buffer empty (8 * sn - pad payload bits were merged in all)
-                    if (neg < 0 || byte_pos != 0 || avail != 0) fail = 1;
+                    // every bit of the quarter must have gone into a symbol: the read position - the bytes not fetched plus what
+                    // the buffer still holds - is where the next quarter began (the stream's first bit for the last one)
+                    if (neg < 0 || 8 * byte_pos + avail != (int)p_end) fail = (QL > 1 && c.ent_off) ? 2u : 1u;
                 }
             }
         }
     }
-    if (fail) dec_fail(info, FQZ_E_ENTROPY);
-    if (ok && sub == 0 && !fail) chunks[id].btype = 3; // done: the general kernel skips it
+    if (fail) dec_fail(info, fail == 2 ? FQZ_DEC_RETRY_GENERAL : FQZ_E_ENTROPY); // (2: the entry points do not fit the stream - or the stream is corrupt: the general path tells)
+    if (ok && li == 0 && !fail) chunks[id].btype = 3; // done: the general kernel skips it
 }
 
 // FQZ-R1 blocks (version-3 files): a wave per group that k_dec_index listed (fqz_rans.h)
@@ -1945,7 +1984,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             if (s != S_QUAL) { hb[b].chunk_base[s] = (uint32_t)(qchunks + chunks); chunks += hb[b].n_chunks[s]; }
             hb[b].frame_base[s] = (uint32_t)nframes;
             nframes += hb[b].n_frames[s];
-            if (general) { hb[b].indexed[s] = 0; hb[b].samp_off[s] = 0; } // the general path walks every payload and every chain, index or not
+            if (general) { hb[b].indexed[s] = 0; hb[b].samp_off[s] = 0; hb[b].ent_off[s] = 0; } // the general path walks every payload and every chain, index or not
             any_indexed |= hb[b].indexed[s] != 0;
             if (hb[b].lz[s]) hb[b].lz[s] = (uint32_t)++n_lz; // 1 + scratch slot
             hi->stream_raw[s] += hb[b].raw_len[s];
@@ -2054,7 +2093,9 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             HIP_TRY(hipEventRecord(d.ev_join2, d.side2));
         }
         if (n_o) {
-            PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_o + HG - 1) / HG), dim3(64), 0, st, d_in, info, dch, darena, dbg, early, n_q, n_o));
+            // (an indexed batch of our own: four lanes per Huffman stream, on the index's entry points)
+            if (!general) PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<4>, dim3((n_o + 3) / 4), dim3(64), 0, st, d_in, info, dch, darena, dbg, early, n_q, n_o));
+            else PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<1>, dim3((n_o + HG - 1) / HG), dim3(64), 0, st, d_in, info, dch, darena, dbg, early, n_q, n_o));
             PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_o), dim3(64), 0, st, d_in, info, dch, darena, early, n_q));
         }
         if (any_seq) { // headers blocks with sequences: their literals are in the scratch now, their triples come from side2
@@ -2068,7 +2109,8 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             PROF(ctx, sd, "k_dec_rans", hipLaunchKernelGGL(k_dec_rans, dim3(rg ? rg : 1), dim3(64), 0, sd, d_in, info, dch, rlist, n_frames, darena));
         }
         if (n_q) {
-            PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((n_q + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late, 0u, n_q));
+            if (!general) PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<4>, dim3((n_q + 3) / 4), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late, 0u, n_q));
+            else PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<1>, dim3((n_q + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late, 0u, n_q));
             PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_q), dim3(64), 0, sd, d_in, info, dch, darena, late, 0u));
         }
         HIP_TRY(hipEventRecord(d.ev_join, d.side)); // the qualities are decoded: the text can be assembled
@@ -2210,7 +2252,7 @@ int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     HIP_TRY(hipMemcpyAsync(&info->n_chunks, &hi->n_chunks, 4, hipMemcpyHostToDevice, st));
     PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, d.chunks.as<DecChunk>(), d.frames.as<DecFrame>(), 1));
     if (nch) {
-        PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf, dim3((nch + HG - 1) / HG), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0, 0x3Fu, 0u, nch));
+        PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<1>, dim3((nch + HG - 1) / HG), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0, 0x3Fu, 0u, nch));
         PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(nch), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0x3Fu, 0u));
         if (nfr) PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((nfr + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, st, d_src, info, d.frames.as<DecFrame>(), nfr, d_dst, 0x3Fu));
     }

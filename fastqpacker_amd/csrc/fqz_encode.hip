@@ -990,7 +990,11 @@ __device__ __forceinline__ uint32_t h2_samples(int s, uint32_t len, uint32_t nre
 {
     return ((s == S_HDR || s == S_PLUS || s == S_NPOS) && nrec > 64 && len != 2 * nrec) ? (nrec - 1) / 64 : 0u;
 }
-__device__ __forceinline__ uint32_t h2_idx_len(uint32_t nch, uint32_t ns) { return 24u + 3u * nch + (ns ? 4u + 4u * ns : 0u); }
+// ent: the index carries the entry points of the Huffman streams behind the samples (FQZ_ENT u16 a block; ent_mask of the kernels
+// below: bit s = stream s has them - every stream but the packed bases and, in a version-3 file, the rANS-coded qualities)
+__device__ __forceinline__ uint32_t h2_ent_at(uint32_t nch, uint32_t ns) { return 24u + 3u * nch + (ns ? 4u + 4u * ns : 0u); }
+__device__ __forceinline__ uint32_t h2_idx_len(uint32_t nch, uint32_t ns, bool ent) { return h2_ent_at(nch, ns) + (ent ? 2u * FQZ_ENT * nch : 0u); }
+#define FQZ_ENT_MASK(flags) (((flags) & FQZ_BATCH_V3) ? 0x3Cu : 0x3Eu)
 __device__ __forceinline__ uint32_t h2_group_bytes(uint32_t len, uint32_t g) { const uint32_t off = g * FQZ_GROUP * FQZ_CHUNK; return len - off < FQZ_GROUP * FQZ_CHUNK ? len - off : FQZ_GROUP * FQZ_CHUNK; }
 __device__ __forceinline__ uint32_t h2_frame_hdr(uint32_t M) { return M < 256u ? 6u : 7u; }
 
@@ -1038,7 +1042,10 @@ __global__ __launch_bounds__(256) void k_group_map(EncInfo *info, const BlockPla
     if (g < group_cap) gmap[g] = d;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_entropy(const EncInfo *info, const uint4 *gmap, const uint8_t *arena, const uint8_t *npos_arena,
+#ifndef ENTROPY_WPE
+#define ENTROPY_WPE 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ENTROPY_WPE, 8))) void k_entropy(const EncInfo *info, const uint4 *gmap, const uint8_t *arena, const uint8_t *npos_arena,
                                                  uint8_t *slots, uint32_t *csize, int dbg_stop, unsigned long long *stamps)
 {
     __shared__ __attribute__((aligned(16))) EntropyLds S;
@@ -1239,7 +1246,8 @@ __device__ __forceinline__ void put_le32(uint8_t *p, uint32_t v) { p[0] = (uint8
 // one 256-thread workgroup, one thread per block: block size = 36 + its six frames, offsets by a workgroup scan
 // prev (nullptr: none): the counters of the launch whose blocks lie in front of this one's in `out` (the first half of a batch that is
 // encoded as two halves in flight): this launch's blocks start behind them
-__global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap, uint32_t hcap, const EncInfo *prev)
+__global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans, const uint32_t *cpre, uint8_t *out, size_t out_cap, uint32_t hcap, const EncInfo *prev,
+                                                uint32_t ent_mask)
 {
     __shared__ uint32_t sh[4];
     if (blockIdx.x) return;
@@ -1263,7 +1271,7 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
             for (int s = 0; s < FQZ_NS; s++) {
                 const uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK, ng = (nch + FQZ_GROUP - 1) / FQZ_GROUP;
                 // index frame + per group (frame header + checksum) + the zstd blocks
-                flen[s] = nch ? h2_idx_len(nch, h2_samples(s, p->len[s], p->nrec)) + 11u * (ng - 1) + h2_frame_hdr(h2_group_bytes(p->len[s], ng - 1)) + 4u +
+                flen[s] = nch ? h2_idx_len(nch, h2_samples(s, p->len[s], p->nrec), (ent_mask >> s) & 1u) + 11u * (ng - 1) + h2_frame_hdr(h2_group_bytes(p->len[s], ng - 1)) + 4u +
                                     (cpre[p->chunk_base[s] + nch] - cpre[p->chunk_base[s]]) : 0;
                 size += flen[s];
             }
@@ -1310,9 +1318,10 @@ __global__ __launch_bounds__(256) void k_layout(EncInfo *info, BlockPlan *plans,
             const uint32_t nch = (p->len[s] + FQZ_CHUNK - 1) / FQZ_CHUNK, ns = h2_samples(s, p->len[s], p->nrec);
             uint8_t *f = out + p->frame_off[s];
             put_le32(f, 0x184D2A50u);
-            put_le32(f + 4, h2_idx_len(nch, ns) - 8);
+            const bool ent = (ent_mask >> s) & 1u;
+            put_le32(f + 4, h2_idx_len(nch, ns, ent) - 8);
             f[8] = 'F'; f[9] = 'Q'; f[10] = 'Z'; f[11] = 'I';
-            f[12] = 1; f[13] = (uint8_t)s; f[14] = ns ? 1 : 0; f[15] = 0; // flags: bit 0 = record samples behind the block sizes
+            f[12] = 1; f[13] = (uint8_t)s; f[14] = (uint8_t)((ns ? 1 : 0) | (ent ? 2 : 0)); f[15] = 0; // flags: bit 0 = record samples behind the block sizes, bit 1 = entry points behind those
             put_le32(f + 16, p->len[s]);
             put_le32(f + 20, nch);
             if (ns) put_le32(f + 24 + 3 * nch, p->nrec); // (k_samples writes the offsets)
@@ -1342,7 +1351,7 @@ __global__ __launch_bounds__(256) void k_samples(const EncInfo *info, const Bloc
 // (cinfo -> plan -> scanned sizes), uniform across the workgroup, so they go through the scalar unit; the body is copied
 // in 16-byte rows aligned to the destination.
 __global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const BlockPlan *plans, const uint8_t *slots, const uint32_t *cpre,
-                                                 const uint32_t *cinfo, const uint32_t *xsum, const uint8_t *arena, uint8_t *out, uint32_t seq_stream)
+                                                 const uint32_t *cinfo, const uint32_t *xsum, const uint8_t *arena, uint8_t *out, uint32_t seq_stream, uint32_t ent_mask)
 {
     const uint32_t chunk = blockIdx.x;
     if (info->status || chunk >= info->n_chunks) return;
@@ -1354,7 +1363,9 @@ __global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const Bloc
     const uint32_t nch = (len + FQZ_CHUNK - 1) / FQZ_CHUNK, g = c / FQZ_GROUP;
     const uint32_t M = h2_group_bytes(len, g), fh = h2_frame_hdr(M);
     uint8_t *const pay = out + p->frame_off[s];
-    uint8_t *dst = pay + h2_idx_len(nch, h2_samples((int)s, len, p->nrec)) + 11u * g + fh + (c0 - cpre[base]);
+    const uint32_t ns = h2_samples((int)s, len, p->nrec);
+    const bool ent = (ent_mask >> s) & 1u;
+    uint8_t *dst = pay + h2_idx_len(nch, ns, ent) + 11u * g + fh + (c0 - cpre[base]);
     uint32_t n = c1 - c0;
     const bool first_in_group = c % FQZ_GROUP == 0, last_in_group = c % FQZ_GROUP == FQZ_GROUP - 1 || c + 1 == nch;
     if (t == 0) {
@@ -1369,6 +1380,11 @@ __global__ __launch_bounds__(256) void k_compact(const EncInfo *info, const Bloc
         if (last_in_group) put_le32(dst + n, xsum[base + g * FQZ_GROUP]); // Content_Checksum: low 32 bits of XXH64 over the group
     }
     const uint8_t *src = slots + (size_t)chunk * FQZ_SLOT;
+    if (ent && t < FQZ_ENT) { // the block's entry points, as the entropy stage left them in the slot
+        const uint32_t v = *(const uint16_t *)(src + FQZ_SLOT_ENT + 2 * t);
+        uint8_t *e = pay + h2_ent_at(nch, ns) + 2u * FQZ_ENT * c + 2 * t;
+        e[0] = (uint8_t)v; e[1] = (uint8_t)(v >> 8);
+    }
     if (s == seq_stream) { // Raw block: 3-byte header, then the chunk's bytes as they lie in the arena
         const uint32_t mk = n - 3, bh = (last_in_group ? 1u : 0u) | (0u << 1) | (mk << 3);
         if (t == 0) { dst[0] = (uint8_t)bh; dst[1] = (uint8_t)(bh >> 8); dst[2] = (uint8_t)(bh >> 16); }
@@ -1759,7 +1775,7 @@ static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes
     PROF(ctx, st, "k_hdr_patch", hipLaunchKernelGGL(k_hdr_patch, dim3(hcap), dim3(64), 0, st, info, hlist, hcap, hside, hsec, slots, csize));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, e.chunk_cap, z_chunks))) return rc;
     if (e.extra.prev_layout) HIP_TRY(hipStreamWaitEvent(st, e.extra.prev_layout, 0)); // (the half in front knows its size)
-    PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap, hcap, e.extra.prev_info));
+    PROF(ctx, st, "k_layout", hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_out, out_cap, hcap, e.extra.prev_info, FQZ_ENT_MASK(flags)));
     if (e.extra.want_layout_event) {
         if (!e.ev_layout) { HIP_TRY(hipEventCreateWithFlags(&e.ev_layout, hipEventDisableTiming)); }
         HIP_TRY(hipEventRecord(e.ev_layout, st));
@@ -1768,7 +1784,7 @@ static int enc_launch_groups(fqz_ctx *ctx, const uint8_t *d_text, size_t n_bytes
         const uint32_t xper = (rpb / 64 + 255) / 256;
         PROF(ctx, st, "k_samples", hipLaunchKernelGGL(k_samples, dim3(xper * e.block_cap * 3), dim3(256), 0, st, info, plans, E, estride, d_out, xper));
     }
-    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, xsum, arena, d_out, (uint32_t)S_SEQ));
+    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(e.chunk_cap), dim3(256), 0, st, info, plans, slots, csize, csize + e.chunk_cap + 2, xsum, arena, d_out, (uint32_t)S_SEQ, FQZ_ENT_MASK(flags)));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
     // (the plans of the first blocks travel with the counters: a caller that asks for block offsets needs no second round trip)
@@ -1978,8 +1994,8 @@ int fqz_enc_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     PROF(ctx, st, "k_entropy", hipLaunchKernelGGL(k_entropy, dim3(group_cap), dim3(256), 0, st, info, e.gmap.as<uint4>(), d_src, d_src, e.slots.as<uint8_t>(), csize, 0, (unsigned long long *)nullptr));
     PROF(ctx, st, "k_xxh", hipLaunchKernelGGL(k_xxh, dim3((group_cap + XXH_PER_WAVE - 1) / XXH_PER_WAVE), dim3(64), 0, st, info, e.xmap.as<uint4>(), d_src, d_src, xsum));
     if ((rc = launch_scan(ctx, "scan_chunks", st, csize, &info->n_chunks, 0, chunks))) return rc;
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_dst, cap, 0u, (const EncInfo *)nullptr);
-    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks ? chunks : 1), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, csize + chunks + 2, xsum, d_src, d_dst, (uint32_t)S_SEQ));
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(256), 0, st, info, plans, csize, d_dst, cap, 0u, (const EncInfo *)nullptr, 0x3Eu);
+    PROF(ctx, st, "k_compact", hipLaunchKernelGGL(k_compact, dim3(chunks ? chunks : 1), dim3(256), 0, st, info, plans, e.slots.as<uint8_t>(), csize, csize + chunks + 2, xsum, d_src, d_dst, (uint32_t)S_SEQ, 0x3Eu));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(e.h_info.p, info, sizeof(EncInfo), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(e.h_plans.p, plans, sizeof(BlockPlan), hipMemcpyDeviceToHost, st));

@@ -665,7 +665,11 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
         const uint8_t *csrc = src + (size_t)k * FQZ_CHUNK;
         uint8_t *slot = slot0 + (size_t)k * FQZ_SLOT;
         const uint32_t lastblk = (last && k + 1 == nchunk) ? 1u : 0u;
+        // the block's entry in the FQZI index (k_compact copies it from here): the bit positions at which a decoder may enter each
+        // of the four Huffman streams (at the symbols lanes 16, 32 and 48 start with); zeros for any other kind of block
+        uint16_t *const ent = (uint16_t *)(slot + FQZ_SLOT_ENT);
         if (same_mask & (1u << k)) { // RLE block: 3-byte header + the byte
+            if (t < FQZ_ENT) ent[t] = 0;
             if (t == 0) {
                 const uint32_t bh = lastblk | (1u << 1) | (mk << 3);
                 *(uint32_t *)slot = (bh & 0xFFFFFF) | ((uint32_t)csrc[0] << 24);
@@ -695,6 +699,7 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
             const uint32_t incl = wave_incl_scan(my_bits);
             const uint32_t tot_bits = __shfl(incl, 63, WAVE);
             const uint32_t bit_off = tot_bits - incl; // bits of all higher lanes = symbols written before mine
+            const uint32_t my_ent = bit_off + my_bits; // bits of my symbols and all behind them: where a decoder enters the stream at my first symbol
             if (lane == 0) S.misc[8 + wave] = tot_bits;
             __syncthreads();
             // ---- sizes, raw fallback, headers (one lane; before any atomicOr touches those words)
@@ -739,6 +744,8 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
             cmode = S.misc[5];
             if (cmode == 2) {
                 uint8_t *o = (uint8_t *)S.out;
+                if (C.nstreams == 4) { if (lane && !(lane & 15)) ent[3 * wave + (lane >> 4) - 1] = (uint16_t)my_ent; }
+                else if (t < FQZ_ENT) ent[t] = 0;
                 if (t < tsz) o[S.misc[14] + t] = tree_byte;
                 __syncthreads();
                 // ---- pass 2: symbols last-to-first, LSB-first bit packing (HUF_compress1X order)
@@ -788,6 +795,7 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
         if (HDR && mode != 2 && nseq) { // no table for this group: the literals of a block with sequences travel raw
             const uint32_t lh = ml < 32 ? 1u : (ml < 4096 ? 2u : 3u), content = lh + ml + sec_sz;
             if (content < mk) {
+                if (t < FQZ_ENT) ent[t] = 0;
                 if (t == 0) {
                     const uint32_t bh = lastblk | (2u << 1) | (content << 3);
                     slot[0] = (uint8_t)bh; slot[1] = (uint8_t)(bh >> 8); slot[2] = (uint8_t)(bh >> 16);
@@ -803,6 +811,7 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
         // raw block: 3-byte header + the mk bytes, copied from global memory (L2-hot) with 128-bit accesses
         {
             const uint32_t bh = lastblk | (0u << 1) | (mk << 3);
+            if (t < FQZ_ENT) ent[t] = 0;
             if (t == 0) { slot[0] = (uint8_t)bh; slot[1] = (uint8_t)(bh >> 8); slot[2] = (uint8_t)(bh >> 16); }
             for (uint32_t off = t * 16; off < mk; off += 256 * 16) {
                 if (off + 16 <= mk) store_u128_unaligned(slot + 3 + off, *(const uint4 *)(csrc + off));

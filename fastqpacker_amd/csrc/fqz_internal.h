@@ -8,6 +8,8 @@
 
 #define FQZ_CHUNK 16384u               // pre-entropy bytes per zstd block (== FQZ_ENTROPY_CHUNK)
 #define FQZ_SLOT (FQZ_CHUNK + 64u)     // per-chunk staging slot in HBM (raw worst case 3+16384, padded for aligned reads)
+#define FQZ_ENT 12u                    // entry points per zstd block in the FQZI index: 3 per Huffman stream (fqz_entropy_dev.h, k_dec_huf)
+#define FQZ_SLOT_ENT (FQZ_CHUNK + 32u) // ... and where the encoder leaves them in the chunk's slot (behind the largest block, 3 + 16384 bytes)
 #define FQZ_GROUP 4u                   // chunks that share one Huffman table (one workgroup of k_entropy)
 #define FQZ_TILE 4096u                 // text bytes per line-index workgroup
 #define FQZ_NS 6

@@ -503,8 +503,16 @@ typedef struct {
 } gchunk;
 
 #define HDR_SSZ_BOUND(n) (((n) < 128 ? 2u : 3u) + ((n) * 66u + 18u + 7u) / 8u) /* count + modes byte + bit stream: <= 66 bits a sequence, 17 flush bits, the end mark */
-static size_t encode_group_chunks(const gchunk *ch, int nch, int force_raw, uint8_t *dst)
+/* ent (NULL: not wanted): per chunk the twelve ENTRY POINTS of its four Huffman streams (FQZI index, flags bit 1), zeros for
+ * any block that is not Huffman-coded in four streams.  A stream of L symbols is written last symbol first, so a decoder reads
+ * symbol 0 first, from the top of the stream down - one lane, L dependent steps.  With per = (ceil(L / 64) + 3) & ~3 (the symbols
+ * a lane of the GPU encoder owns) the stream is cut at the symbols e_j = min(16 j per, L), j = 1..3, and the entry point E_j is
+ * the number of bits the symbols [e_j, L) take = the bit position (LSB-first from the stream's first byte) right above the code
+ * of symbol e_j: a decoder lane starts there and decodes the symbols [e_j, e_j+1) without waiting for the lane in front of it. */
+#define FQZO_ENT 12
+static size_t encode_group_chunks(const gchunk *ch, int nch, int force_raw, uint8_t *dst, uint16_t (*ent)[FQZO_ENT])
 {
+    if (ent) memset(ent, 0, sizeof(uint16_t) * FQZO_ENT * (size_t)nch);
     uint32_t count[256] = {0};
     size_t M = 0;
     for (int k = 0; k < nch; k++) { for (uint32_t i = 0; i < ch[k].n_lit; i++) count[ch[k].lit[i]]++; M += ch[k].n_lit; }
@@ -608,6 +616,15 @@ static size_t encode_group_chunks(const gchunk *ch, int nch, int force_raw, uint
                 size_t a = (size_t)q * seg, b = (q == nstreams - 1) ? m : a + seg;
                 (void)huf_stream(c + a, b - a, code, nbits, op);
                 op += ssize[q];
+                if (ent && nstreams == 4) {
+                    const size_t L = b - a, per = ((L + 63) / 64 + 3) & ~(size_t)3;
+                    for (int j = 1; j <= 3; j++) {
+                        const size_t e = 16 * (size_t)j * per < L ? 16 * (size_t)j * per : L;
+                        uint32_t bits = 0;
+                        for (size_t i = a + e; i < b; i++) bits += nbits[c[i]];
+                        ent[k][3 * q + j - 1] = (uint16_t)bits; /* <= 4096 symbols x 11 bits */
+                    }
+                }
             }
         }
         if (nseq) { memcpy(op, seqsec, ssz); op += ssz; }
@@ -619,7 +636,7 @@ static size_t encode_group_chunks(const gchunk *ch, int nch, int force_raw, uint
 }
 
 /* a group of plain chunks: M consecutive bytes cut every FQZO_CHUNK */
-static size_t encode_group_ex(const uint8_t *src, size_t M, int last, int force_raw, uint8_t *dst)
+static size_t encode_group_ex(const uint8_t *src, size_t M, int last, int force_raw, uint8_t *dst, uint16_t (*ent)[FQZO_ENT])
 {
     (void)last; /* every group is a frame of its own: its last chunk carries the Last_Block bit */
     gchunk ch[FQZO_GROUP];
@@ -629,9 +646,9 @@ static size_t encode_group_ex(const uint8_t *src, size_t M, int last, int force_
         ch[nch].raw = ch[nch].lit = src + off; ch[nch].mk = ch[nch].n_lit = m; ch[nch].sq = NULL; ch[nch].nseq = 0;
         nch++;
     }
-    return encode_group_chunks(ch, nch, force_raw, dst);
+    return encode_group_chunks(ch, nch, force_raw, dst, ent);
 }
-size_t fqzo_encode_group(const uint8_t *src, size_t M, int last, uint8_t *dst) { return encode_group_ex(src, M, last, 0, dst); }
+size_t fqzo_encode_group(const uint8_t *src, size_t M, int last, uint8_t *dst) { return encode_group_ex(src, M, last, 0, dst, NULL); }
 
 /* a single chunk = a group of one */
 size_t fqzo_encode_chunk(const uint8_t *src, size_t m, int last, uint8_t *dst) { return fqzo_encode_group(src, m, last, dst); }
@@ -826,7 +843,7 @@ size_t fqzo_entropy_bound(size_t n)
 {
     if (!n) return 0;
     const size_t chunks = (n + FQZO_CHUNK - 1) / FQZO_CHUNK, groups = (chunks + FQZO_GROUP - 1) / FQZO_GROUP;
-    return FQZO_IDX_HDR + 3 * chunks + (4 + 4 * (n / 128 + 1)) /* record samples: a record is >= 2 bytes */ + groups * (7 + 4) + n + 3 * chunks;
+    return FQZO_IDX_HDR + (3 + 2 * FQZO_ENT) * chunks + (4 + 4 * (n / 128 + 1)) /* record samples: a record is >= 2 bytes */ + groups * (7 + 4) + n + 3 * chunks;
 }
 
 size_t fqzo_entropy_encode_stream(const uint8_t *src, size_t n, int stream, uint8_t *dst) { return fqzo_entropy_encode_stream_v(src, n, stream, 2, dst); }
@@ -849,12 +866,16 @@ size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, in
      * without walking the chain from the start (it checks them against the walk it does between two samples).  Not for
      * streams whose records are all bare prefixes (offset = 2 x record) */
     const uint32_t ns = (rs && nr > 64 && n != 2 * (size_t)nr) ? (nr - 1) / 64 : 0;
-    const size_t idx_len = FQZO_IDX_HDR + 3 * chunks + (ns ? 4 + 4 * (size_t)ns : 0);
+    /* entry points of the Huffman streams (encode_group_chunks): every stream but the packed bases (Raw blocks by definition) and
+     * the rANS-coded qualities of a version-3 file */
+    const int has_ent = stream != 0 && !(version == 3 && stream == 1);
+    const size_t ent_at = FQZO_IDX_HDR + 3 * chunks + (ns ? 4 + 4 * (size_t)ns : 0);
+    const size_t idx_len = ent_at + (has_ent ? 2 * FQZO_ENT * chunks : 0);
     uint8_t *idx = dst, *op = dst + idx_len;
     put32le(idx, 0x184D2A50u);
     put32le(idx + 4, (uint32_t)(idx_len - 8));
     idx[8] = 'F'; idx[9] = 'Q'; idx[10] = 'Z'; idx[11] = 'I';
-    idx[12] = 1; idx[13] = (uint8_t)stream; idx[14] = ns ? 1 : 0; idx[15] = 0; /* flags: bit 0 = record samples present */
+    idx[12] = 1; idx[13] = (uint8_t)stream; idx[14] = (uint8_t)((ns ? 1 : 0) | (has_ent ? 2 : 0)); idx[15] = 0; /* flags: bit 0 = record samples, bit 1 = entry points */
     put32le(idx + 16, (uint32_t)n);
     put32le(idx + 20, (uint32_t)chunks);
     uint8_t *ent = idx + FQZO_IDX_HDR;
@@ -868,6 +889,8 @@ size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, in
     hseq *sqbuf = rs ? (hseq *)malloc(sizeof(hseq) * FQZO_GROUP * HDR_MAX_SEQ) : NULL;
     uint8_t *litbuf = rs ? (uint8_t *)malloc(G) : NULL;
     hseq lseq[FQZO_GROUP]; /* lengths stream: a chunk of equal u32 values = its first value + one match at offset 4 */
+    uint16_t gent[FQZO_GROUP][FQZO_ENT];
+    uint8_t *entp = idx + ent_at;
     for (size_t off = 0; off < n; off += G) {
         const size_t M = n - off < G ? n - off : G;
         op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD;
@@ -886,7 +909,7 @@ size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, in
                 ch[nch].nseq = hdr_chunk_model(src, rs, nr, (uint32_t)(off + co), mk, sqbuf + (size_t)nch * HDR_MAX_SEQ, litbuf + co, &nl);
                 ch[nch].n_lit = nl;
             }
-            body = encode_group_chunks(ch, nch, 0, op);
+            body = encode_group_chunks(ch, nch, 0, op, has_ent ? gent : NULL);
         } else if (version == 3 && stream == 1) body = encode_group_rans(src + off, M, op); /* FQZ-R1 */
         else if (stream == 5) {
             /* u32 read lengths (compress.go:501): fixed-length reads make the stream 4-periodic, which an order-0 coder cannot see
@@ -905,8 +928,8 @@ size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, in
                     if (same) { lseq[nch].ll = 4; lseq[nch].ml = mk - 4; lseq[nch].off = 4; ch[nch].sq = &lseq[nch]; ch[nch].nseq = 1; ch[nch].n_lit = 4; }
                 }
             }
-            body = encode_group_chunks(ch, nch, 0, op);
-        } else body = encode_group_ex(src + off, M, 1, stream == 0, op);
+            body = encode_group_chunks(ch, nch, 0, op, has_ent ? gent : NULL);
+        } else body = encode_group_ex(src + off, M, 1, stream == 0, op, has_ent ? gent : NULL);
         /* the index lists the size of every zstd block of the group */
         for (size_t q = 0; q < body;) {
             const uint32_t bh = op[q] | ((uint32_t)op[q + 1] << 8) | ((uint32_t)op[q + 2] << 16);
@@ -915,6 +938,11 @@ size_t fqzo_entropy_encode_stream_v(const uint8_t *src, size_t n, int stream, in
             ent[0] = (uint8_t)sz; ent[1] = (uint8_t)(sz >> 8); ent[2] = (uint8_t)(sz >> 16);
             ent += 3;
             q += sz;
+        }
+        if (has_ent) {
+            const size_t gch = (M + FQZO_CHUNK - 1) / FQZO_CHUNK;
+            for (size_t k = 0; k < gch; k++)
+                for (int j = 0; j < FQZO_ENT; j++) { *entp++ = (uint8_t)gent[k][j]; *entp++ = (uint8_t)(gent[k][j] >> 8); }
         }
         op += body;
         put32le(op, (uint32_t)fqzo_xxh64(src + off, M, 0));
@@ -1002,7 +1030,7 @@ size_t fqzo_seg_frame(const uint8_t *src, size_t n, int stream, uint8_t *dst)
             }
         }
     }
-    op += encode_group_chunks(ch, nch, stream == 0, op);
+    op += encode_group_chunks(ch, nch, stream == 0, op, NULL);
     put32le(op, (uint32_t)fqzo_xxh64(src, n, 0));
     op += 4;
     free(rs); free(sqbuf); free(litbuf);

@@ -281,7 +281,7 @@ def compress(fastq, block_size=0, workers=1, batch_records=0, entropy=0, force_e
     a = np.frombuffer(fastq, dtype=np.uint8) if not isinstance(fastq, np.ndarray) else fastq
     cap = lib().fqzo_compress_bound(a.size)
     if batch_records:  # tiny blocks: 36-byte block headers and six frame headers per block dwarf the library's bound
-        cap += (int(np.count_nonzero(a == 10)) // 4 // batch_records + 2) * 320
+        cap += (int(np.count_nonzero(a == 10)) // 4 // batch_records + 2) * 480
     out = np.empty(cap, dtype=np.uint8)
     opt = Options(block_size, workers, batch_records, entropy, force_encoding, block_index, framing)
     r = lib().fqzo_compress(a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, C.byref(opt))

@@ -133,7 +133,7 @@ def test_record_samples_are_a_hint(fq):
     hdr = [int.from_bytes(good[10 + 4 * i: 14 + 4 * i], "little") for i in range(9)]
     h_off = 10 + 36 + hdr[1] + hdr[2]
     pay = good[h_off: h_off + hdr[3]]
-    assert pay[8:12] == b"FQZI" and pay[14] == 1                      # flags: samples present
+    assert pay[8:12] == b"FQZI" and pay[14] == 3                      # flags: samples and entry points present
     nch = int.from_bytes(pay[20:24], "little")
     at = 24 + 3 * nch
     assert int.from_bytes(pay[at:at + 4], "little") == 1000             # the record count they were made for
@@ -151,3 +151,35 @@ def test_record_samples_are_a_hint(fq):
         bad = bytearray(good)
         bad[h_off + at + 4 + 4 * k] ^= 0x10
         assert fq.compress.Decompress(bytes(bad)) == text
+
+
+@pytest.mark.gpu
+def test_entry_points_are_a_hint(fq):
+    """The index frames carry, per zstd block, three entry points into each of its four Huffman streams (FQZI flags bit 1): the
+    decoder's quarter-lanes start there.  They are what the oracle says (the bits of the symbols behind the entry), every stock
+    decoder ignores them, and a wrong one must not change the result: a quarter that does not end where the next one began sends
+    the batch to the general path, which reads the streams from their end marks."""
+    text = make_fastq(3000, seed=36, min_len=100, max_len=150)
+    good = fq.compress.Compress(text)
+    assert good == O.compress(text)                                   # (two implementations computed the same entry points)
+    hdr = [int.from_bytes(good[10 + 4 * i: 14 + 4 * i], "little") for i in range(9)]
+    q_off = 10 + 36 + hdr[1]
+    pay = good[q_off: q_off + hdr[2]]
+    assert pay[8:12] == b"FQZI" and pay[13] == 1 and pay[14] == 2      # the quality payload: entry points, no record samples
+    nch = int.from_bytes(pay[20:24], "little")
+    assert nch >= 10
+    at = 24 + 3 * nch
+    ent = np.frombuffer(pay[at: at + 24 * nch], dtype="<u2").reshape(nch, 4, 3).astype(np.int64)
+    sizes = [int.from_bytes(pay[24 + 3 * c: 27 + 3 * c], "little") for c in range(nch)]
+    assert (ent[:, :, 0] >= ent[:, :, 1]).all() and (ent[:, :, 1] >= ent[:, :, 2]).all()
+    assert (ent[0] > 0).all() and (ent[0, :, 0] < 8 * sizes[0]).all()   # a full block: every quarter has bits
+    # (the seq payload - Raw blocks by definition - carries none)
+    assert good[10 + 36 + 8: 10 + 36 + 12] == b"FQZI" and good[10 + 36 + 14] == 0
+    assert fq.compress.Decompress(good) == text
+    for c, j, flip in ((0, 0, 0x01), (0, 5, 0x80), (nch - 1, 11, 0x02), (3, 7, 0xFF)):
+        bad = bytearray(good)
+        bad[q_off + at + 24 * c + 2 * j] ^= flip
+        assert fq.compress.Decompress(bytes(bad)) == text
+    bad = bytearray(good)
+    bad[q_off + at: q_off + at + 24 * nch] = b"\xff" * (24 * nch)
+    assert fq.compress.Decompress(bytes(bad)) == text

@@ -1,12 +1,10 @@
 #!/bin/bash
-# A/B of environment switches inside ONE gpurun call: tools/ab_env.sh "" "FQZ_X=1" ...   (prints encode ms and decode MB/s)
-for rep in 1 2; do
-for cfg in "$@"; do
-  env $cfg python bench.py --no-cpu --steps 3 --inflight 0 --decode-steps 6 2>/dev/null | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d = json.loads(l); print('[$cfg]', 'enc_ms', d['ms_per_step'], 'dec_MBps', d['decode_MBps'])
-"
-done
+# A/B of an environment switch on the default bench: tools/ab_env.sh VAR [steps]   (VAR=0 against VAR=1, three runs each, interleaved)
+V=$1; S=${2:-10}
+for i in 1 2 3; do
+  for x in 0 1; do
+    env $V=$x python bench.py --no-supp --no-cpu --no-v3 --inflight 0 --decode-steps 1 --steps $S --warmup 3 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$V=$x', d['ms_per_step'], d['value'], d['roundtrip_bit_exact'])"
+  done
 done
