@@ -113,7 +113,8 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     for (DevBuf *b : db) b->release();
     d.h_info.release(); d.h_blocks.release();
     if (d.side) { (void)hipStreamSynchronize(d.side); (void)hipStreamDestroy(d.side); (void)hipEventDestroy(d.ev_fork); (void)hipEventDestroy(d.ev_join);
-                  (void)hipStreamSynchronize(d.side2); (void)hipStreamDestroy(d.side2); (void)hipEventDestroy(d.ev_join2); (void)hipEventDestroy(d.ev_x); (void)hipEventDestroy(d.ev_joinx); }
+                  (void)hipStreamSynchronize(d.side2); (void)hipStreamDestroy(d.side2); (void)hipEventDestroy(d.ev_join2); (void)hipEventDestroy(d.ev_x); (void)hipEventDestroy(d.ev_joinx);
+                  (void)hipEventDestroy(d.ev_huf); (void)hipEventDestroy(d.ev_seq); }
     c->prof.collect();
     for (hipEvent_t ev : c->prof.pool) (void)hipEventDestroy(ev);
     for (fqz_ctx *lane : c->lanes) fqz_ctx_destroy(lane);

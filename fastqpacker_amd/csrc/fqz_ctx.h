@@ -129,7 +129,7 @@ struct DecState {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;            // bases + qualities are entropy-decoded here while the record walks run on `stream`
     hipStream_t side2 = nullptr;           // the sequence bit streams of the headers blocks (needs the input only)
-    hipEvent_t ev_join2 = nullptr, ev_x = nullptr, ev_joinx = nullptr;
+    hipEvent_t ev_join2 = nullptr, ev_x = nullptr, ev_joinx = nullptr, ev_huf = nullptr, ev_seq = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool in_flight = false;
     DevBuf info, blocks, chunks, frames, streams, rec, partials, tables, lz_scratch;

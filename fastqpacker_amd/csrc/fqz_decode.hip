@@ -942,6 +942,7 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
             ok = (lh + lsize + (c.seq_len ? c.seq_len : 1u) == c.csize && (c.seq_len || src[lh + lsize] == 0) && regen >= 4) ? 1u : 0u;
         }
     }
+    if (dbg == 3) return; // timing experiment: the block's literals header only
     if (ok && li == 0) {
         // weights -> g.l1 (as bytes), FSE scratch -> g.syms
         uint8_t *w = (uint8_t *)g.l1;
@@ -959,6 +960,7 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
             if (used <= tree_lim) nw = fse_decode_weights_dev(ip + 1, hb, w, 255, g.syms, g.syms + 64, (uint16_t *)(g.syms + 128));
         }
         uint32_t good = 0, table_log = 0;
+        if (dbg == 4) return; // timing experiment: ... and the weights read
         if (nw > 0) {
             uint32_t total = 0, cnt[14];
             for (int r = 0; r < 14; r++) cnt[r] = 0;
@@ -1162,22 +1164,21 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *in, DecInfo *inf
     if (failed) dec_fail(info, FQZ_E_ENTROPY);
 }
 
-__global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena, uint32_t stream_mask, uint32_t first)
+// One wave per workgroup takes the chunks first + blockIdx.x, + gridDim.x, ...: most chunks of a launch are not its business (another
+// launch's stream, done by k_dec_huf), and a workgroup per chunk - tens of thousands that need their LDS only to find that out -
+// queue behind whatever holds the chip's LDS at the time (the qualities' Huffman decode: 0.26 - 0.44 ms for this kernel).
+__device__ __forceinline__ void dec_entropy_chunk(const uint8_t *in, DecInfo *info, const DecChunk &c, uint8_t *arena, uint16_t *s_dt, uint8_t *s_w, uint8_t *s_scratch, int *s_i)
 {
-    __shared__ uint16_t s_dt[4096];
-    __shared__ uint8_t s_w[260];
-    __shared__ uint8_t s_scratch[256];
-    __shared__ int s_i[8]; // 0 table log, 1 tree bytes used (or -1), 2..5 per-stream result
-    const uint32_t id = first + blockIdx.x;
-    if (id >= info->n_chunks || info->status) return;
-    const DecChunk c = chunks[id];
-    if (c.btype >= 3 || !((stream_mask >> c.stream) & 1u)) return; // decoded by k_dec_huf (3) / k_dec_rans (4) / another launch's stream
     const uint8_t *src = in + c.src_off;
     uint8_t *dst = arena + c.dst_off;
     const uint32_t lane = threadIdx.x;
     if (c.btype == 0) { // raw block (2-bit packed bases): 128-bit copies, the source is unaligned
-        const uint32_t full = c.regen & ~15u;
-        for (uint32_t i = lane * 16; i < full; i += 64 * 16) store_u128_unaligned(dst + i, load_u128_unaligned(src + i));
+        const uint32_t full = c.regen & ~15u, quads = full & ~4095u;
+        for (uint32_t i = lane * 16; i < quads; i += 4096) { // four loads in flight a lane
+            const uint4 a = load_u128_unaligned(src + i), b = load_u128_unaligned(src + i + 1024), e = load_u128_unaligned(src + i + 2048), f = load_u128_unaligned(src + i + 3072);
+            store_u128_unaligned(dst + i, a); store_u128_unaligned(dst + i + 1024, b); store_u128_unaligned(dst + i + 2048, e); store_u128_unaligned(dst + i + 3072, f);
+        }
+        for (uint32_t i = quads + lane * 16; i < full; i += 64 * 16) store_u128_unaligned(dst + i, load_u128_unaligned(src + i));
         for (uint32_t i = full + lane; i < c.regen; i += 64) dst[i] = src[i];
         return;
     }
@@ -1230,6 +1231,22 @@ __global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *
         uint32_t sn = lane == 0 ? z1 : (lane == 1 ? z2 : (lane == 2 ? z3 : z4));
         uint32_t cnt = lane < 3 ? seg : regen - 3 * seg;
         if (huf_decode_stream_dev(ip + so, sn, s_dt, table_log, dst + lane * seg, cnt) < 0) dec_fail(info, FQZ_E_ENTROPY);
+    }
+}
+#define DENT_GRID 4096u
+__global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena, uint32_t stream_mask, uint32_t first, uint32_t count)
+{
+    __shared__ uint16_t s_dt[4096];
+    __shared__ uint8_t s_w[260];
+    __shared__ uint8_t s_scratch[256];
+    __shared__ int s_i[8]; // 0 table log, 1 tree bytes used (or -1), 2..5 per-stream result
+    if (info->status) return;
+    const uint32_t end = first + count < info->n_chunks ? first + count : info->n_chunks;
+    for (uint32_t id = first + blockIdx.x; id < end; id += gridDim.x) {
+        const DecChunk c = chunks[id];
+        if (c.btype >= 3 || !((stream_mask >> c.stream) & 1u)) continue; // decoded by k_dec_huf (3) / k_dec_rans (4) / another launch's stream
+        dec_entropy_chunk(in, info, c, arena, s_dt, s_w, s_scratch, s_i);
+        __syncthreads(); // (one wave: orders its LDS traffic before the next chunk's table)
     }
 }
 
@@ -2067,28 +2084,33 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     // at the end needs the bases and qualities too.  The latter are 3/4 of the entropy decode and the walks leave the
     // chip almost empty, so the two run side by side: bases + qualities on the context's side stream, joined before
     // k_dec_assemble (285 -> 295 GB/s over 30 decodes, A/B on one box).
-    // (the packed bases are Raw blocks in our files - a plain copy: it rides on the caller's stream, which has slack beside
-    //  the record walks, and leaves the side stream to the Huffman decode of the qualities, the longest item of the decode)
+    // (the packed bases are Raw blocks in our files - a plain copy of a tenth of the text, needed by the assembly only: it rides
+    //  on the second side stream, behind the sequences' bit streams, off the chain that leads to the record walks)
     const uint32_t early = (1u << S_HDR) | (1u << S_PLUS) | (1u << S_NPOS) | (1u << S_LEN) | (1u << S_SEQ), late = 1u << S_QUAL;
     bool forked = false;
     if (n_chunks) {
         const int dbg = getenv("FQZ_DBG_DEC") ? atoi(getenv("FQZ_DBG_DEC")) : 0;
         if (!d.side) {
-            HIP_TRY(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking)); // (at the lowest stream priority: 320 instead of 390 GB/s, A/B on one box)
+            // (a CU mask that keeps the qualities' long Huffman decode off a part of the chip: 406 - 446 against 498 GB/s; the lowest
+            //  stream priority for it: 320 against 390 GB/s; holding it back behind the headers chain: 457 against 520 GB/s)
+            HIP_TRY(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&d.ev_joinx, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
             HIP_TRY(hipStreamCreateWithFlags(&d.side2, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&d.ev_join2, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&d.ev_x, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&d.ev_huf, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&d.ev_seq, hipEventDisableTiming));
         }
         static const bool dbg_serial = getenv("FQZ_DBG_SERIAL") && atoi(getenv("FQZ_DBG_SERIAL")); // diagnostic runs: one stream (standalone kernel times)
         const hipStream_t sd = dbg_serial ? st : d.side;
         HIP_TRY(hipEventRecord(d.ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(d.side, d.ev_fork, 0));
+        const hipStream_t s2 = dbg_serial ? st : d.side2;
+        const uint32_t seqm = 1u << S_SEQ;
+        HIP_TRY(hipStreamWaitEvent(d.side2, d.ev_fork, 0));
         if (any_seq) { // the sequence bit streams need the input only: a chain of serial steps, beside the literals' Huffman decode
-            const hipStream_t s2 = dbg_serial ? st : d.side2;
-            HIP_TRY(hipStreamWaitEvent(d.side2, d.ev_fork, 0));
             PROF(ctx, s2, "k_dec_seq_fse", hipLaunchKernelGGL(k_dec_seq_fse, dim3((n_o + 15) / 16), dim3(64), 0, s2, d_in, info, dch, darena, n_q));
             HIP_TRY(hipEventRecord(d.ev_join2, d.side2));
         }
@@ -2096,8 +2118,13 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             // (an indexed batch of our own: four lanes per Huffman stream, on the index's entry points)
             if (!general) PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<4>, dim3((n_o + 3) / 4), dim3(64), 0, st, d_in, info, dch, darena, dbg, early, n_q, n_o));
             else PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<1>, dim3((n_o + HG - 1) / HG), dim3(64), 0, st, d_in, info, dch, darena, dbg, early, n_q, n_o));
-            PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_o), dim3(64), 0, st, d_in, info, dch, darena, early, n_q));
+            PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_o < DENT_GRID ? n_o : DENT_GRID), dim3(64), 0, st, d_in, info, dch, darena, early & ~seqm, n_q, n_o));
+            // the bases: behind the Huffman launch above (which takes what a foreign file has Huffman-coded of them and marks it done)
+            HIP_TRY(hipEventRecord(d.ev_huf, st));
+            HIP_TRY(hipStreamWaitEvent(d.side2, d.ev_huf, 0));
+            PROF(ctx, s2, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_o < DENT_GRID ? n_o : DENT_GRID), dim3(64), 0, s2, d_in, info, dch, darena, seqm, n_q, n_o));
         }
+        HIP_TRY(hipEventRecord(d.ev_seq, d.side2));
         if (any_seq) { // headers blocks with sequences: their literals are in the scratch now, their triples come from side2
             HIP_TRY(hipStreamWaitEvent(st, d.ev_join2, 0));
             PROF(ctx, st, "k_dec_seq_exec", hipLaunchKernelGGL(k_dec_seq_exec, dim3(n_o), dim3(64), 0, st, info, dch, darena, n_q));
@@ -2111,7 +2138,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         if (n_q) {
             if (!general) PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<4>, dim3((n_q + 3) / 4), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late, 0u, n_q));
             else PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<1>, dim3((n_q + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late, 0u, n_q));
-            PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_q), dim3(64), 0, sd, d_in, info, dch, darena, late, 0u));
+            PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_q < DENT_GRID ? n_q : DENT_GRID), dim3(64), 0, sd, d_in, info, dch, darena, late, 0u, n_q));
         }
         HIP_TRY(hipEventRecord(d.ev_join, d.side)); // the qualities are decoded: the text can be assembled
         if (n_frames) { // content checksums of the decoded frames, all on the side stream: nothing needs them before the verdict at the
@@ -2120,6 +2147,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             HIP_TRY(hipEventRecord(d.ev_x, st));
             PROF(ctx, sd, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, sd, d_in, info, dfr, n_frames, darena, late));
             HIP_TRY(hipStreamWaitEvent(d.side, d.ev_x, 0));
+            HIP_TRY(hipStreamWaitEvent(d.side, d.ev_seq, 0));
             PROF(ctx, sd, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((n_frames + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, sd, d_in, info, dfr, n_frames, darena, early));
         }
         HIP_TRY(hipEventRecord(d.ev_joinx, d.side));
@@ -2164,10 +2192,10 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         if (g > 8192) g = 8192;
         if (!g) g = 1;
         uint32_t qoff = qual_encoding == FQZ_ENCODING_PHRED64 ? 64u : 33u;
-        if (forked) { HIP_TRY(hipStreamWaitEvent(st, d.ev_join, 0)); forked = false; }
+        if (forked) { HIP_TRY(hipStreamWaitEvent(st, d.ev_join, 0)); HIP_TRY(hipStreamWaitEvent(st, d.ev_seq, 0)); forked = false; }
         if (!skip_assemble) PROF(ctx, st, "k_dec_assemble", hipLaunchKernelGGL(k_dec_assemble, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride, qoff, d_out));
     }
-    if (forked) HIP_TRY(hipStreamWaitEvent(st, d.ev_join, 0)); // (no records: nothing assembled, still join)
+    if (forked) { HIP_TRY(hipStreamWaitEvent(st, d.ev_join, 0)); HIP_TRY(hipStreamWaitEvent(st, d.ev_seq, 0)); } // (no records: nothing assembled, still join)
     if (n_chunks) HIP_TRY(hipStreamWaitEvent(st, d.ev_joinx, 0)); // the checksums: before the status is read
     HIP_TRY(hipGetLastError());
     // keep the host-side per-stream totals; status / out_len come back after the tail
@@ -2253,7 +2281,7 @@ int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, d.chunks.as<DecChunk>(), d.frames.as<DecFrame>(), 1));
     if (nch) {
         PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<1>, dim3((nch + HG - 1) / HG), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0, 0x3Fu, 0u, nch));
-        PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(nch), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0x3Fu, 0u));
+        PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(nch < DENT_GRID ? nch : DENT_GRID), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0x3Fu, 0u, nch));
         if (nfr) PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((nfr + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, st, d_src, info, d.frames.as<DecFrame>(), nfr, d_dst, 0x3Fu));
     }
     HIP_TRY(hipGetLastError());
