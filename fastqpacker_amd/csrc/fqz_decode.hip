@@ -900,6 +900,7 @@ struct HufGroupLds {
     uint8_t syms[256];          // symbols sorted by (weight, symbol); aliases the FSE scratch
     uint16_t rs[16];            // rs[w]: first TL-bit table index of weight w (rs[TL+1] = 1 << TL)
     uint16_t ss[16];            // ss[w]: first position in syms[] of weight w
+    uint32_t cnt[16];           // table build by the block's lanes together: symbols per weight, then the next free place in syms[] per weight; 14 total, 15 bad
 };
 
 // (the launch covers the chunks [first, first + count): the host numbers the chunks of the quality streams first, so that the
@@ -943,6 +944,89 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
         }
     }
     if (dbg == 3) return; // timing experiment: the block's literals header only
+    if constexpr (QL > 1) {
+        // The tree description -> canonical order, by the block's LPB lanes together (one lane alone spends as long on it - a
+        // byte, a dependent LDS access at a time - as on a quarter of a stream: 0.2 of the kernel's 0.47 ms):
+        //   weights   the direct form (what our encoder writes for <= 128 weights): a lane per byte; FSE-compressed: the leader, serially
+        //   counts    per weight with LDS atomics; the leader derives the table log, the implied last weight and the ranges
+        //   symbols   sorted by (weight, symbol), LPB at a time: a symbol's place = its weight's next free place + the number of
+        //             lanes below it that hold the same weight (a ballot per weight)
+        uint8_t *w = (uint8_t *)g.l1;
+        const uint8_t *ip = treeless ? in + c.tree_off : src + lh;
+        const uint32_t tree_lim = treeless ? c.tree_len : lsize;
+        const uint32_t lead = lane - li, bmask = (1u << LPB) - 1u;
+        int nw = -1;
+        if (ok) {
+            const uint32_t hb = ip[0];
+            if (hb >= 128) {
+                nw = (int)hb - 127;
+                used = 1 + (uint32_t)(nw + 1) / 2;
+                if (used > tree_lim) nw = -1;
+                else for (int k = (int)li; 2 * k < nw; k += (int)LPB) { const uint32_t b = ip[1 + k]; w[2 * k] = (uint8_t)(b >> 4); if (2 * k + 1 < nw) w[2 * k + 1] = (uint8_t)(b & 15); }
+            } else {
+                used = 1 + hb;
+                if (li == 0 && used <= tree_lim) nw = fse_decode_weights_dev(ip + 1, hb, w, 255, g.syms, g.syms + 64, (uint16_t *)(g.syms + 128));
+            }
+            g.cnt[li] = 0; // (LPB = 16 = the array)
+        }
+        nw = __shfl(nw, (int)lead, WAVE); // (the FSE form: the leader knows)
+        if (dbg == 4) return; // timing experiment: ... and the weights read
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (ok && nw > 0) {
+            uint32_t tot = 0, bad = 0;
+            for (int i = (int)li; i < nw; i += (int)LPB) { const uint32_t x = w[i]; if (x > 12) bad = 1; else { tot += (1u << x) >> 1; atomicAdd(&g.cnt[x], 1u); } }
+            if (tot) atomicAdd(&g.cnt[14], tot);
+            if (bad) atomicOr(&g.cnt[15], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t good = 0, table_log = 0;
+        if (ok && nw > 0 && li == 0) {
+            const uint32_t total = g.cnt[14];
+            if (!g.cnt[15] && total) {
+                table_log = (uint32_t)highbit32_d(total) + 1;
+                const uint32_t rest = (1u << table_log) - total;
+                if (table_log <= 11 && !(rest & (rest - 1))) {
+                    const uint32_t lw = (uint32_t)highbit32_d(rest) + 1;
+                    w[nw] = (uint8_t)lw;
+                    g.cnt[lw]++;
+                    if (g.cnt[1] >= 2 && !(g.cnt[1] & 1)) {
+                        uint32_t r = 0, q = 0;
+                        for (uint32_t x = 1; x <= table_log; x++) { const uint32_t n = g.cnt[x]; g.rs[x] = (uint16_t)r; g.ss[x] = (uint16_t)q; g.cnt[x] = q; r += n << (x - 1); q += n; }
+                        g.rs[table_log + 1] = (uint16_t)r; // = 1 << table_log for a complete code
+                        g.ss[table_log + 1] = (uint16_t)q;
+                        good = r == (1u << table_log);
+                    }
+                }
+            }
+        }
+        good = __shfl(good, (int)lead, WAVE);
+        table_log = __shfl(table_log, (int)lead, WAVE);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        ok = ok && good;
+        const int nsym = ok ? nw + 1 : 0; // (with the implied last weight)
+        static_assert(LPB == 16, "g.cnt is cleared a lane an entry");
+        for (int rd = 0; __ballot(rd * (int)LPB < nsym) != 0; rd++) { // (the wave's blocks go round together: the ballots are the wave's)
+            const int sy = rd * (int)LPB + (int)li;
+            const uint32_t x = sy < nsym ? w[sy] : 0u;
+            uint32_t below = 0, same = 0;
+            for (uint32_t xx = 1; xx <= 11; xx++) {
+                const uint32_t m = (uint32_t)(__ballot(x == xx) >> lead) & bmask;
+                if (x == xx) { below = __popc(m & ((1u << li) - 1u)); same = __popc(m); }
+            }
+            uint32_t at = 0;
+            if (x) at = g.cnt[x] + below;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (x) { g.syms[at] = (uint8_t)sy; if (!below) g.cnt[x] += same; } // overwrites the FSE scratch: done with it
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        tl = table_log;
+        if (treeless) used = 0; // nothing of this block's literals section is a tree
+    } else
     if (ok && li == 0) {
         // weights -> g.l1 (as bytes), FSE scratch -> g.syms
         uint8_t *w = (uint8_t *)g.l1;
