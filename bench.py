@@ -388,7 +388,7 @@ def main():
         # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
         # separately; summary committed under profiles/): static evidence, not re-measured in this process
         traffic = None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")))
                 if abs(in_bytes / launches_per_step - pmc.get("batch_bytes", 0)) <= 0.02 * in_bytes and dom in pmc["kernels"]:

@@ -3,6 +3,8 @@
 #include <string.h>
 #include "fqz_internal.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -177,6 +179,18 @@ struct Prof {
     }
     void collect() // call after the stream has been synchronised
     {
+        // FQZ_DBG_TIMELINE=1 (diagnostic): start and duration of every bracketed launch of the batch, from the events themselves -
+        // the order of things as they run without a profiler's dispatch overhead (tools/timeline.py needs a rocprofv3 trace)
+        static const bool tl = getenv("FQZ_DBG_TIMELINE") && atoi(getenv("FQZ_DBG_TIMELINE"));
+        if (tl && !pending.empty()) {
+            fprintf(stderr, "[fqz timeline] %zu launches\n", pending.size());
+            for (ProfEntry &e : pending) {
+                float t0 = 0, d = 0;
+                (void)hipEventElapsedTime(&t0, pending.front().a, e.a);
+                (void)hipEventElapsedTime(&d, e.a, e.b);
+                fprintf(stderr, "[fqz timeline] %9.1f us  +%8.1f us  %s\n", t0 * 1e3, d * 1e3, e.name);
+            }
+        }
         for (ProfEntry &e : pending) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
