@@ -283,9 +283,12 @@ struct FrameWalk {
     uint32_t fcs_lo, fcs_hi, has_fcs, lz, frame_lz;
     uint32_t tree_off, tree_len; // last Huffman tree description seen in the frame (for treeless blocks)
     uint32_t frame_regen_lo, frame_regen_hi, total_lo, total_hi;
+    uint32_t fch, rtab;          // FQZ-R1: chunk index at the frame's start; 0, or 1 + the place in the frame of the block that carries the frequency table
 };
 
-__global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint32_t in_bytes, DecInfo *info, DecBlock *blocks, DecChunk *chunks, DecFrame *frames, int pass)
+// rlist (version-3 files, else nullptr): the walk announces the rANS groups it finds to k_dec_rans, as k_dec_index does for indexed payloads
+__global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint32_t in_bytes, DecInfo *info, DecBlock *blocks, DecChunk *chunks, DecFrame *frames, int pass,
+                                                         int v3, uint2 *rlist, uint32_t rcap)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[2][FRAME_BUF];
     __shared__ FrameWalk W;
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
         } else {
             // wave 0, every lane with the same values: the chain of block headers is walked with scalar instructions
             uint32_t pos = UNI(W.pos), nch = UNI(W.nch), dst = UNI(W.dst), in_frame = UNI(W.in_frame), ck = UNI(W.ck), st = 0;
-            uint32_t nfr = UNI(W.nfr), fstart = UNI(W.fstart);
+            uint32_t nfr = UNI(W.nfr), fstart = UNI(W.fstart), fch = UNI(W.fch), rtab = UNI(W.rtab);
             uint32_t has_fcs = UNI(W.has_fcs), lz = UNI(W.lz), frame_lz = UNI(W.frame_lz), tree_off = UNI(W.tree_off), tree_len = UNI(W.tree_len);
             unsigned long long fcs = ((unsigned long long)UNI(W.fcs_hi) << 32) | UNI(W.fcs_lo);
             unsigned long long frame_regen = ((unsigned long long)UNI(W.frame_regen_hi) << 32) | UNI(W.frame_regen_lo);
@@ -368,6 +371,8 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                     frame_lz = 0;
                     tree_len = 0;
                     fstart = dst;
+                    fch = nch;
+                    rtab = 0;
                     continue;
                 }
                 // block header (3 bytes) and the literals header behind it (<= 5 bytes) in one LDS round trip; everything
@@ -389,7 +394,10 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                 const uint32_t n_huf = fmt <= 1 ? 3u : (fmt == 2 ? 4u : 5u);
                 const uint32_t need = lt2 <= 1 ? n_plain : n_huf;
                 const uint32_t csize = type == 1 ? 1u : bs;
-                uint32_t regen = type == 2 ? (lt2 <= 1 ? r_plain : r_huf) : bs;
+                // FQZ-R1 block (type 3, fqz_rans.h): m u16 | tflag | ...; the first one of a frame carries the table, and only that one
+                const uint32_t m3 = (h0 >> 24) | ((h1 & 0xFFu) << 8), tflag = (h1 >> 8) & 0xFFu;
+                const bool r3_ok = (v3 != 0) & (s == S_QUAL) & (bs >= 3 + 64) & ((tflag & ~1u) == 0) & ((tflag != 0) == (rtab == 0)) & (m3 >= 1) & (m3 <= FQZ_CHUNK);
+                uint32_t regen = type == 3 ? m3 : (type == 2 ? (lt2 <= 1 ? r_plain : r_huf) : bs);
                 // a block of ours ends right after the literals with Number_of_Sequences = 0; anything longer carries LZ sequences
                 const uint32_t c_huf = fmt <= 1 ? ((lh >> 14) & 0x3FFu) : (fmt == 2 ? ((lh >> 18) & 0x3FFFu) : (((lh >> 22) | ((h1 >> 24) << 10)) & 0x3FFFFu));
                 const uint32_t lit_total = need + (lt2 == 0 ? r_plain : (lt2 == 1 ? 1u : c_huf));
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                     frame_lz = 1;
                     regen = 0;
                 }
-                const bool bad = (n - pos < 3) | (type == 3) | ((type == 2) & ((bs < need) | (bs > 128 * 1024))) | (csize > n - cpos) | (regen > 128 * 1024);
+                const bool bad = (n - pos < 3) | ((type == 3) & !r3_ok) | ((type == 2) & ((bs < need) | (bs > 128 * 1024))) | (csize > n - cpos) | (regen > 128 * 1024);
                 if (bad) { st = 2; break; }
                 if (out && (pass == 1 || nch < n_expected)) {
                     if (t == 0) {
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                         c.csize = csize;
                         c.dst_off = dst;
                         c.regen = regen;
-                        c.btype = type;
+                        c.btype = type == 3 ? 4u : type; // (4: k_dec_rans)
                         c.tree_off = (type == 2 && lt2 == 3) ? tree_off : 0;
                         c.tree_len = (type == 2 && lt2 == 3) ? tree_len : 0;
                         c.stream = (uint32_t)s;
@@ -424,10 +432,19 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
                     dst += regen;
                 }
                 if (type == 2 && lt2 == 2) { tree_off = p0 + cpos + need; tree_len = c_huf; } // this block's tree serves the treeless ones after it
+                if (type == 3 && tflag) rtab = nch - fch + 1;
                 nch++;
                 pos = cpos + csize;
                 frame_regen += regen;
                 if (last) {
+                    if (rtab) { // the frame's rANS group: its chunks and the one with the table
+                        if (nch - fch > FQZ_GROUP) { st = 2; break; }
+                        if (out && rlist && (pass == 1 || nch <= n_expected) && t == 0) {
+                            const uint32_t r = atomicAdd(&info->n_rgroups, 1u);
+                            if (r < rcap) rlist[r] = make_uint2(UNI(b->chunk_base[s]) + fch, (nch - fch) | ((rtab - 1) << 8));
+                        }
+                        rtab = 0;
+                    }
                     if (ck && n - pos < 4) { st = 2; break; }
                     if (frame_lz) frame_regen = fcs;
                     if (has_fcs && fcs != frame_regen) { st = 2; break; }
@@ -444,7 +461,7 @@ __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint
             }
             if (t == 0) {
                 W.pos = pos; W.nch = nch; W.dst = dst; W.in_frame = in_frame; W.ck = ck; W.state = st; W.has_fcs = has_fcs; W.lz = lz; W.frame_lz = frame_lz; W.tree_off = tree_off; W.tree_len = tree_len;
-                W.nfr = nfr; W.fstart = fstart;
+                W.nfr = nfr; W.fstart = fstart; W.fch = fch; W.rtab = rtab;
                 W.fcs_lo = (uint32_t)fcs; W.fcs_hi = (uint32_t)(fcs >> 32);
                 W.frame_regen_lo = (uint32_t)frame_regen; W.frame_regen_hi = (uint32_t)(frame_regen >> 32);
                 W.total_lo = (uint32_t)regen_total; W.total_hi = (uint32_t)(regen_total >> 32);
@@ -2056,7 +2073,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         HIP_TRY(hipMemsetAsync(info, 0, sizeof(DecInfo), st));
         HIP_TRY(hipMemsetAsync(blocks, 0, sizeof(DecBlock) * (size_t)nb, st));
         PROF(ctx, st, "k_dec_blocks", hipLaunchKernelGGL(k_dec_blocks, dim3(1), dim3(64), 0, st, d_in, n, (uint32_t)version, info, blocks, nb));
-        if (general) PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, (DecChunk *)nullptr, (DecFrame *)nullptr, 0));
+        if (general) PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, (DecChunk *)nullptr, (DecFrame *)nullptr, 0, version == FQZ_VERSION3 ? 1 : 0, (uint2 *)nullptr, 0u));
         else PROF(ctx, st, "k_dec_fhdr", hipLaunchKernelGGL(k_dec_fhdr, dim3((fgrid + 63) / 64), dim3(64), 0, st, d_in, info, blocks, nb));
         HIP_TRY(hipMemcpyAsync(hi, info, sizeof(DecInfo), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(d.h_blocks.p, blocks, sizeof(DecBlock) * (size_t)nb, hipMemcpyDeviceToHost, st));
@@ -2162,7 +2179,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     hi->n_chunks = n_chunks;
     HIP_TRY(hipMemcpyAsync(&info->n_chunks, &hi->n_chunks, 4, hipMemcpyHostToDevice, st));
     // ---- bulk kernels
-    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, dch, dfr, general ? 1 : 2));
+    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, dch, dfr, general ? 1 : 2, version == FQZ_VERSION3 ? 1 : 0, rlist, n_frames));
     if (any_indexed) PROF(ctx, st, "k_dec_index", hipLaunchKernelGGL(k_dec_index, dim3(fgrid), dim3(256), 0, st, d_in, info, blocks, dch, dfr, rlist, n_frames));
     // The record walks and the size scans below need only the header / plus / nPos / lengths streams, the text assembly
     // at the end needs the bases and qualities too.  The latter are 3/4 of the entropy decode and the walks leave the
@@ -2335,7 +2352,7 @@ int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     *hi = z;
     HIP_TRY(hipMemcpyAsync(info, hi, sizeof z, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(blocks, hb, sizeof *hb, hipMemcpyHostToDevice, st));
-    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, (DecChunk *)nullptr, (DecFrame *)nullptr, 0));
+    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, (DecChunk *)nullptr, (DecFrame *)nullptr, 0, 0, (uint2 *)nullptr, 0u));
     HIP_TRY(hipMemcpyAsync(hi, info, sizeof z, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hb, blocks, sizeof *hb, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -2362,7 +2379,7 @@ int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     hi->n_chunks = nch;
     HIP_TRY(hipMemcpyAsync(blocks, hb, sizeof *hb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(&info->n_chunks, &hi->n_chunks, 4, hipMemcpyHostToDevice, st));
-    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, d.chunks.as<DecChunk>(), d.frames.as<DecFrame>(), 1));
+    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, d.chunks.as<DecChunk>(), d.frames.as<DecFrame>(), 1, 0, (uint2 *)nullptr, 0u));
     if (nch) {
         PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<1>, dim3((nch + HG - 1) / HG), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0, 0x3Fu, 0u, nch));
         PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(nch < DENT_GRID ? nch : DENT_GRID), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0x3Fu, 0u, nch));

@@ -4,6 +4,8 @@
 the oracle is the specification, the GPU must write the same bytes and both must read each other's files."""
 import struct
 
+import os
+
 import numpy as np
 import pytest
 
@@ -127,6 +129,13 @@ def test_gpu_v3_matches_oracle_and_round_trips(fq):
         assert got == want, name
         assert fq.compress.Decompress(got) == text, name
         assert O.decompress(got) == text, name
+        # the general path (what a payload falls back to when its index does not add up): the frame walk finds the
+        # rANS groups itself
+        os.environ["FQZ_DEC_GENERAL"] = "1"
+        try:
+            assert fq.compress.Decompress(got) == text, name
+        finally:
+            del os.environ["FQZ_DEC_GENERAL"]
         # and the version-2 path is what it was
         assert fq.compress.Compress(text) == O.compress(text), name
 
