@@ -1,5 +1,5 @@
 /*
- * fqz_entropy.c — oracle for the entropy stage ("FQZ-H1" profile).
+ * fqz_entropy.c — oracle for the entropy stage (the "FQZ-H2" profile of DESIGN.md section 4; FQZ-R1 and FQZ-S1 further down).
  *
  * TEST INFRASTRUCTURE ONLY (see fqz_oracle.h).
  *
@@ -9,22 +9,26 @@
  * zstd.Decoder.DecodeAll (compress.go:785-814).  That library
  * (github.com/klauspost/compress v1.19.1, go.mod:8) is not on disk; its
  * compressed bytes are pinned by no reference test ("parity unpinned").  What
- * IS a contract is the wire format: each payload is a zstd frame (RFC 8878).
- * This file restates the published format for the subset we emit:
+ * IS a contract is the wire format: each payload is a sequence of zstd frames
+ * (RFC 8878) that DecodeAll joins.  This file restates the published format
+ * for the subset we emit (fqzo_entropy_encode_stream_v has the full layout):
  *
- *   frame  = magic 28 B5 2F FD | FHD 0x80 | Window_Descriptor 0x38 (128 KiB)
- *            | Frame_Content_Size u32le | blocks...            (no checksum)
- *   block  = one per FQZO_CHUNK (16 KiB) bytes of the stream, in order:
- *            RLE block        when all bytes are equal,
- *            Raw block        when m < 64, when the histogram is near-flat
- *                             (sum of squared counts * 230 <= m^2) or Huffman does not shrink it,
- *            Compressed block = Huffman-coded literals (1 stream if m < 256,
- *            else 4 streams) + "0 sequences".
+ *   payload = [skippable index frame 'FQZI'] + one frame per GROUP of four
+ *             16 KiB chunks: magic | FHD (Single_Segment, Content_Checksum,
+ *             Frame_Content_Size) | one block per chunk | XXH64 low 32 bits
+ *   block   = RLE block        when all bytes are equal,
+ *             Raw block        when the group is < 64 bytes, near-flat
+ *                              (sum of squared counts * 230 <= M^2), the packed
+ *                              bases, or Huffman does not shrink the chunk,
+ *             Compressed block = Huffman-coded literals (1 stream if m < 256,
+ *             else 4 streams; one table per group, later blocks treeless) +
+ *             "0 sequences" - or, for modelled headers / lengths chunks,
+ *             sequences on the predefined FSE tables.
  *   empty stream -> 0 bytes (klauspost EncodeAll without WithZeroFrames).
  *
  * The construction below is fully deterministic; the HIP encoder
  * (fastqpacker_amd/csrc) implements the same steps and must match it
- * byte-for-byte (tests/test_gpu_parity.py).
+ * byte-for-byte (tests/test_gpu_encode.py, test_gpu_fuzz.py, test_gpu_fullsize.py).
  */
 #include "fqz_oracle.h"
 
@@ -146,7 +150,7 @@ static inline uint8_t *bw_close(bitw *b) /* end mark 1 + pad */
     return b->p;
 }
 
-/* FQZ-H1 does not fit a distribution to the weights of every chunk: it picks one of two fixed normalised
+/* The profile does not fit a distribution to the weights of every group: it picks one of two fixed normalised
  * distributions over the weight values 0..11 (table log 5), by the share of zero weights (absent symbols).  The
  * compressed description grows by ~15 bytes per chunk against a fitted table, and the encoder saves the serial
  * count / normalise / NCount / table-build steps — 15 % of the GPU entropy kernel.  (A zstd encoder is free to
@@ -300,7 +304,7 @@ static size_t huf_stream(const uint8_t *src, size_t n, const uint16_t *code, con
     return (size_t)(bw_close(&bw) - dst);
 }
 
-/* One GROUP of up to FQZO_GROUP consecutive 16 KiB chunks = up to 64 KiB of a stream.  FQZ-H1 builds ONE Huffman
+/* One GROUP of up to FQZO_GROUP consecutive 16 KiB chunks = up to 64 KiB of a stream.  The profile builds ONE Huffman
  * table per group, from the histogram of the whole group: the first Compressed block of the group carries the tree
  * description, the others are "treeless" (Literals_Block_Type 3, RFC 8878 3.1.1.3.1.1: reuse the previous table).
  * On the GPU the table build (sort, Huffman merge, FSE weight coding) is a quarter of the LDS traffic of a chunk; a
@@ -833,7 +837,7 @@ uint64_t fqzo_xxh64(const uint8_t *p, size_t len, uint64_t seed)
  *             the size of each (3 bytes, block header included) - what a parallel decoder needs to find every block
  *             without walking the chain of block headers;
  *   [frames]  one zstd frame per GROUP of FQZO_GROUP chunks (<= 64 KiB of the stream): Single_Segment, Frame_Content_Size,
- *             Content_Checksum; one zstd block per 16 KiB chunk as in FQZ-H1 (one Huffman table per group, the later
+ *             Content_Checksum; one zstd block per 16 KiB chunk (one Huffman table per group, the later
  *             blocks treeless).  The 2-bit packed bases (stream 0) are Raw blocks by definition.
  * Frames are independent, so encoder and decoder work on every group in parallel and the content checksum (an
  * inherently serial hash) runs over 64 KiB at a time, one hash per four lanes. */
