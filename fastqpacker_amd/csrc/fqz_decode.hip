@@ -948,16 +948,18 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
     HufGroupLds &g = G[grp];
     // ---- per block: parse the literals header and the tree description (one lane per block)
     uint32_t ok = 0, tl = 0, lh = 0, lsize = 0, used = 0, regen = c.regen;
-    bool treeless = false;
+    bool treeless = false, one = false, huf_lit = false; // huf_lit: a Compressed block with Huffman-coded literals - this kernel's business
     const uint8_t *src = in + c.src_off;
     if (have && c.btype == 2 && c.csize >= 5) {
         uint32_t type = src[0] & 3, fmt = (src[0] >> 2) & 3;
         treeless = type == 3 && c.tree_len != 0; // the table comes from the tree of an earlier block of the frame
-        if ((type == 2 || treeless) && fmt >= 1) {
-            if (fmt == 1) { lh = 3; lsize = (rd24(src) >> 14) & 0x3FF; }
+        if (type == 2 || treeless) {
+            one = fmt == 0; // a single stream (fewer than 256 literals: the last block of a stream, a well-matched headers chunk)
+            if (fmt <= 1) { lh = 3; lsize = (rd24(src) >> 14) & 0x3FF; }
             else if (fmt == 2) { lh = 4; lsize = rd32(src) >> 18; }
             else { lh = 5; lsize = (rd32(src) >> 22) | ((uint32_t)src[4] << 10); }
-            ok = (lh + lsize + (c.seq_len ? c.seq_len : 1u) == c.csize && (c.seq_len || src[lh + lsize] == 0) && regen >= 4) ? 1u : 0u;
+            ok = (lh + lsize + (c.seq_len ? c.seq_len : 1u) == c.csize && (c.seq_len || src[lh + lsize] == 0) && regen >= (one ? 1u : 4u)) ? 1u : 0u;
+            huf_lit = true;
         }
     }
     if (dbg == 3) return; // timing experiment: the block's literals header only
@@ -1118,22 +1120,26 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
     if (ok) {
         const uint8_t *ip = src + lh + used;
         uint32_t rem = lsize - used;
-        if (rem < 10) fail = 1;
+        uint32_t z1 = 0, z2 = 0, z3 = 0;
+        const uint32_t seg = one ? regen : (regen + 3) / 4;
+        bool geo = rem >= (one ? 1u : 10u);
+        if (geo && !one) {
+            z1 = rd16(ip); z2 = rd16(ip + 2); z3 = rd16(ip + 4);
+            geo = !(6 + z1 + z2 + z3 >= rem || 3 * seg > regen);
+        }
+        if (!geo) fail = 1;
         else {
-            uint32_t z1 = rd16(ip), z2 = rd16(ip + 2), z3 = rd16(ip + 4);
-            uint32_t seg = (regen + 3) / 4;
-            if (6 + z1 + z2 + z3 >= rem || 3 * seg > regen) fail = 1;
-            else {
-                uint32_t z4 = rem - 6 - z1 - z2 - z3;
-                uint32_t so = 6 + (sub > 0 ? z1 : 0) + (sub > 1 ? z2 : 0) + (sub > 2 ? z3 : 0);
-                uint32_t sn = sub == 0 ? z1 : (sub == 1 ? z2 : (sub == 2 ? z3 : z4));
-                const uint32_t L = sub < 3 ? seg : regen - 3 * seg; // symbols of the stream
+            {
+                const uint32_t z4 = rem - 6 - z1 - z2 - z3; // (four streams)
+                const uint32_t so = one ? 0u : 6 + (sub > 0 ? z1 : 0) + (sub > 1 ? z2 : 0) + (sub > 2 ? z3 : 0);
+                const uint32_t sn = one ? rem : (sub == 0 ? z1 : (sub == 1 ? z2 : (sub == 2 ? z3 : z4)));
+                const uint32_t L = one ? regen : (sub < 3 ? seg : regen - 3 * seg); // symbols of the stream
                 // my quarter: symbols [e_lo, e_hi), bits [p_end, p_top) of the stream (LSB-first from its first byte; the
                 // stream is read from the top down)
                 uint32_t e_lo = 0, e_hi = L, p_end = 0;
                 int p_top = -1; // -1: from the end mark
                 if (QL > 1) {
-                    if (c.ent_off) {
+                    if (c.ent_off && !one) {
                         const uint32_t per = ((L + 63) / 64 + 3) & ~3u, q16 = 16 * per;
                         const uint8_t *ep = in + c.ent_off + 2 * (3 * sub);
                         e_lo = qt * q16 < L ? qt * q16 : L;
@@ -1143,8 +1149,8 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                     } else if (qt) e_lo = e_hi = L; // no entry points: the first quarter decodes the stream
                 }
                 uint32_t cnt = e_hi - e_lo;
-                const bool idle = QL > 1 && qt && !c.ent_off;
-                uint8_t *dst = arena + c.dst_off + sub * seg + e_lo;
+                const bool idle = (QL > 1 && qt && (!c.ent_off || one)) || (one && sub); // (a single stream: the block's first lane)
+                uint8_t *dst = arena + c.dst_off + (one ? 0u : sub * seg) + e_lo;
                 // 128-bit bit buffer (hi:lo, next bits at the MSB end of hi), four symbols per iteration.  The loads that
                 // top the buffer up are issued at the START of an iteration and merged at its END, so their latency
                 // overlaps four symbol decodes and no load is in flight across the loop back-edge (hipcc copies
@@ -1246,13 +1252,17 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                     }
                     // every bit of the quarter must have gone into a symbol: the read position - the bytes not fetched plus what
                     // the buffer still holds - is where the next quarter began (the stream's first bit for the last one)
-                    if (neg < 0 || 8 * byte_pos + avail != (int)p_end) fail = (QL > 1 && c.ent_off) ? 2u : 1u;
+                    if (neg < 0 || 8 * byte_pos + avail != (int)p_end) fail = (QL > 1 && c.ent_off && !one) ? 2u : 1u;
                 }
             }
         }
     }
     if (fail) dec_fail(info, fail == 2 ? FQZ_DEC_RETRY_GENERAL : FQZ_E_ENTROPY); // (2: the entry points do not fit the stream - or the stream is corrupt: the general path tells)
     if (ok && li == 0 && !fail) chunks[id].btype = 3; // done: the general kernel skips it
+    // an indexed batch (QL > 1) has no fallback kernel behind this one on its critical chain (k_dec_entropy, 145 registers a lane,
+    // would wait for the qualities' decode to leave room): Huffman-coded literals this kernel does not take - a tree it refuses -
+    // send the batch to the general path, which has it and names the error
+    if (QL > 1 && huf_lit && !ok && li == 0) dec_fail(info, FQZ_DEC_RETRY_GENERAL);
 }
 
 // FQZ-R1 blocks (version-3 files): a wave per group that k_dec_index listed (fqz_rans.h)
@@ -1268,7 +1278,9 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *in, DecInfo *inf
 // One wave per workgroup takes the chunks first + blockIdx.x, + gridDim.x, ...: most chunks of a launch are not its business (another
 // launch's stream, done by k_dec_huf), and a workgroup per chunk - tens of thousands that need their LDS only to find that out -
 // queue behind whatever holds the chip's LDS at the time (the qualities' Huffman decode: 0.26 - 0.44 ms for this kernel).
-__device__ __forceinline__ void dec_entropy_chunk(const uint8_t *in, DecInfo *info, const DecChunk &c, uint8_t *arena, uint16_t *s_dt, uint8_t *s_w, uint8_t *s_scratch, int *s_i)
+// what needs no table: Raw and RLE blocks, and Compressed blocks whose literals are raw or RLE (the lengths chunks: 4 literals and
+// a match).  Returns false for Huffman-coded literals (dec_entropy_chunk).
+__device__ __forceinline__ bool dec_plain_chunk(const uint8_t *in, DecInfo *info, const DecChunk &c, uint8_t *arena)
 {
     const uint8_t *src = in + c.src_off;
     uint8_t *dst = arena + c.dst_off;
@@ -1281,25 +1293,35 @@ __device__ __forceinline__ void dec_entropy_chunk(const uint8_t *in, DecInfo *in
         }
         for (uint32_t i = quads + lane * 16; i < full; i += 64 * 16) store_u128_unaligned(dst + i, load_u128_unaligned(src + i));
         for (uint32_t i = full + lane; i < c.regen; i += 64) dst[i] = src[i];
-        return;
+        return true;
     }
     if (c.btype == 1) {
         const uint32_t v4 = (uint32_t)src[0] * 0x01010101u, full = c.regen & ~15u;
         for (uint32_t i = lane * 16; i < full; i += 64 * 16) store_u128_unaligned(dst + i, make_uint4(v4, v4, v4, v4));
         for (uint32_t i = full + lane; i < c.regen; i += 64) dst[i] = (uint8_t)v4;
-        return;
+        return true;
     }
-    // Compressed block: literals section + "0 sequences"
-    uint32_t n = c.csize;
-    uint32_t type = src[0] & 3, fmt = (src[0] >> 2) & 3, lh, regen = c.regen, lsize = 0, nstreams = 1;
+    // Compressed block with raw / RLE literals
+    const uint32_t n = c.csize, type = src[0] & 3, fmt = (src[0] >> 2) & 3, regen = c.regen;
     if (type <= 1) {
-        lh = (fmt == 0 || fmt == 2) ? 1 : (fmt == 1 ? 2 : 3);
-        lsize = type == 0 ? regen : 1;
-        if (lh + lsize + (c.seq_len ? c.seq_len : 1u) != n || (!c.seq_len && src[lh + lsize] != 0)) { dec_fail(info, FQZ_E_ENTROPY); return; }
+        const uint32_t lh = (fmt == 0 || fmt == 2) ? 1 : (fmt == 1 ? 2 : 3), lsize = type == 0 ? regen : 1;
+        if (lh + lsize + (c.seq_len ? c.seq_len : 1u) != n || (!c.seq_len && src[lh + lsize] != 0)) { dec_fail(info, FQZ_E_ENTROPY); return true; }
         if (type == 0) for (uint32_t i = lane; i < regen; i += 64) dst[i] = src[lh + i];
         else { uint8_t v = src[lh]; for (uint32_t i = lane; i < regen; i += 64) dst[i] = v; }
-        return;
+        return true;
     }
+    return false;
+}
+// Compressed block with Huffman-coded literals that k_dec_huf left (one stream; a tree it would not take): literals section + "0 sequences"
+__device__ __forceinline__ void dec_entropy_chunk(const uint8_t *in, DecInfo *info, const DecChunk &c, uint8_t *arena, uint16_t *s_dt, uint8_t *s_w, uint8_t *s_scratch, int *s_i)
+{
+    const uint8_t *src = in + c.src_off;
+    uint8_t *dst = arena + c.dst_off;
+    const uint32_t lane = threadIdx.x;
+    if (c.btype != 2) return;
+    uint32_t n = c.csize;
+    uint32_t type = src[0] & 3, fmt = (src[0] >> 2) & 3, lh, regen = c.regen, lsize = 0, nstreams = 1;
+    if (type <= 1) return; // (dec_plain_chunk)
     if (fmt <= 1) { lh = 3; lsize = (rd24(src) >> 14) & 0x3FF; nstreams = fmt ? 4 : 1; }
     else if (fmt == 2) { lh = 4; lsize = rd32(src) >> 18; nstreams = 4; }
     else { lh = 5; lsize = (rd32(src) >> 22) | ((uint32_t)src[4] << 10); nstreams = 4; }
@@ -1335,6 +1357,21 @@ __device__ __forceinline__ void dec_entropy_chunk(const uint8_t *in, DecInfo *in
     }
 }
 #define DENT_GRID 4096u
+// The two kernels below are what runs on the critical chain while the qualities' Huffman decode (80 VGPRs a wave, five or six waves a
+// SIMD) holds most of every register file: a wave of theirs starts only where its own registers still fit.  With 145 VGPRs - the
+// fallback decoder's table build - the one kernel that did both jobs waited 0.25 ms for places to run 0.03 ms of copies.  So the
+// copies have a kernel of their own (a few registers, no LDS), k_dec_huf takes single-stream blocks too, and the fallback runs on the
+// general path only (an indexed batch that needs it is redone there).
+__global__ __launch_bounds__(64) void k_dec_plain(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena, uint32_t stream_mask, uint32_t first, uint32_t count)
+{
+    if (info->status) return;
+    const uint32_t end = first + count < info->n_chunks ? first + count : info->n_chunks;
+    for (uint32_t id = first + blockIdx.x; id < end; id += gridDim.x) {
+        const DecChunk c = chunks[id];
+        if (c.btype >= 3 || !((stream_mask >> c.stream) & 1u)) continue;
+        (void)dec_plain_chunk(in, info, c, arena);
+    }
+}
 __global__ __launch_bounds__(64) void k_dec_entropy(const uint8_t *in, DecInfo *info, const DecChunk *chunks, uint8_t *arena, uint32_t stream_mask, uint32_t first, uint32_t count)
 {
     __shared__ uint16_t s_dt[4096];
@@ -2219,11 +2256,13 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
             // (an indexed batch of our own: four lanes per Huffman stream, on the index's entry points)
             if (!general) PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<4>, dim3((n_o + 3) / 4), dim3(64), 0, st, d_in, info, dch, darena, dbg, early, n_q, n_o));
             else PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<1>, dim3((n_o + HG - 1) / HG), dim3(64), 0, st, d_in, info, dch, darena, dbg, early, n_q, n_o));
-            PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_o < DENT_GRID ? n_o : DENT_GRID), dim3(64), 0, st, d_in, info, dch, darena, early & ~seqm, n_q, n_o));
+            PROF(ctx, st, "k_dec_plain", hipLaunchKernelGGL(k_dec_plain, dim3(n_o < DENT_GRID ? n_o : DENT_GRID), dim3(64), 0, st, d_in, info, dch, darena, early & ~seqm, n_q, n_o));
+            if (general) PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_o < DENT_GRID ? n_o : DENT_GRID), dim3(64), 0, st, d_in, info, dch, darena, early & ~seqm, n_q, n_o));
             // the bases: behind the Huffman launch above (which takes what a foreign file has Huffman-coded of them and marks it done)
             HIP_TRY(hipEventRecord(d.ev_huf, st));
             HIP_TRY(hipStreamWaitEvent(d.side2, d.ev_huf, 0));
-            PROF(ctx, s2, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_o < DENT_GRID ? n_o : DENT_GRID), dim3(64), 0, s2, d_in, info, dch, darena, seqm, n_q, n_o));
+            PROF(ctx, s2, "k_dec_plain", hipLaunchKernelGGL(k_dec_plain, dim3(n_o < DENT_GRID ? n_o : DENT_GRID), dim3(64), 0, s2, d_in, info, dch, darena, seqm, n_q, n_o));
+            if (general) PROF(ctx, s2, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_o < DENT_GRID ? n_o : DENT_GRID), dim3(64), 0, s2, d_in, info, dch, darena, seqm, n_q, n_o));
         }
         HIP_TRY(hipEventRecord(d.ev_seq, d.side2));
         if (any_seq) { // headers blocks with sequences: their literals are in the scratch now, their triples come from side2
@@ -2239,7 +2278,8 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         if (n_q) {
             if (!general) PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<4>, dim3((n_q + 3) / 4), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late, 0u, n_q));
             else PROF(ctx, sd, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<1>, dim3((n_q + HG - 1) / HG), dim3(64), 0, sd, d_in, info, dch, darena, dbg, late, 0u, n_q));
-            PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_q < DENT_GRID ? n_q : DENT_GRID), dim3(64), 0, sd, d_in, info, dch, darena, late, 0u, n_q));
+            PROF(ctx, sd, "k_dec_plain", hipLaunchKernelGGL(k_dec_plain, dim3(n_q < DENT_GRID ? n_q : DENT_GRID), dim3(64), 0, sd, d_in, info, dch, darena, late, 0u, n_q));
+            if (general) PROF(ctx, sd, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(n_q < DENT_GRID ? n_q : DENT_GRID), dim3(64), 0, sd, d_in, info, dch, darena, late, 0u, n_q));
         }
         HIP_TRY(hipEventRecord(d.ev_join, d.side)); // the qualities are decoded: the text can be assembled
         if (n_frames) { // content checksums of the decoded frames, all on the side stream: nothing needs them before the verdict at the
@@ -2382,6 +2422,7 @@ int fqz_dec_entropy_only(fqz_ctx *ctx, const uint8_t *d_src, size_t n, uint8_t *
     PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(1), dim3(FRAME_NT), 0, st, d_src, (uint32_t)n, info, blocks, d.chunks.as<DecChunk>(), d.frames.as<DecFrame>(), 1, 0, (uint2 *)nullptr, 0u));
     if (nch) {
         PROF(ctx, st, "k_dec_huf", hipLaunchKernelGGL(k_dec_huf<1>, dim3((nch + HG - 1) / HG), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0, 0x3Fu, 0u, nch));
+        PROF(ctx, st, "k_dec_plain", hipLaunchKernelGGL(k_dec_plain, dim3(nch < DENT_GRID ? nch : DENT_GRID), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0x3Fu, 0u, nch));
         PROF(ctx, st, "k_dec_entropy", hipLaunchKernelGGL(k_dec_entropy, dim3(nch < DENT_GRID ? nch : DENT_GRID), dim3(64), 0, st, d_src, info, d.chunks.as<DecChunk>(), d_dst, 0x3Fu, 0u, nch));
         if (nfr) PROF(ctx, st, "k_dec_xxh", hipLaunchKernelGGL(k_dec_xxh, dim3((nfr + DXXH_PER_WAVE - 1) / DXXH_PER_WAVE), dim3(64), 0, st, d_src, info, d.frames.as<DecFrame>(), nfr, d_dst, 0x3Fu));
     }
