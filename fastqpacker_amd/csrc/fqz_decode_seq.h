@@ -154,7 +154,10 @@ __global__ __launch_bounds__(64) void k_dec_seq_fse(const uint8_t *in, DecInfo *
     uint32_t bad_profile = 0, bad_data = 0;
     uint2 held = make_uint2(0, 0);
     for (uint32_t i = 0; i < (verdict ? 0u : nseq); i++) { // one rarely-taken branch a step; everything else is straight-line
-        if (p - 80 < 8 * wb && wb > 0) window();
+        // the window is refilled by all sixteen blocks of the wave together, when the first of them runs short: a refill is a global
+        // round trip the whole wave waits for (1-2 us), and with every block refilling on its own schedule - each every ~35
+        // sequences - some block did in every other step (0.28 ms for chains that take 0.06)
+        if (__ballot(p - 80 < 8 * wb && wb > 0) != 0ull) { if (wb > 0) window(); }
         const uint2 e = T.tab[cc][st & 63];
         const bool last = i + 1 == nseq;
         const uint32_t xb = e.y >> 24, sb = last ? 0u : (e.x >> 8) & 0xFF;
