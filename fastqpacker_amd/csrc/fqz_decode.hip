@@ -112,6 +112,7 @@ __global__ void k_dec_blocks(const uint8_t *in, uint32_t n, uint32_t version, De
     }
     info->n_blocks = nb;
     info->n_rec = nrec;
+    info->n_groups = (nrec + 63) / 64;
 }
 
 // ---------------------------------------------------------------------------
@@ -1651,8 +1652,11 @@ __device__ __forceinline__ uint32_t find_block(const DecBlock *blocks, uint32_t 
 
 // btot[block][3]: 64-bit sums of the three columns per block: the 32-bit columns (and their scans) may wrap for a crafted
 // block, the totals that the truncation checks compare may not
+// gsum[c][g]: the sum of column c over the records [64 g, 64 g + 64) (as 32-bit values, like the columns).  The offsets that
+// k_dec_assemble needs are prefix sums of the columns; only the group sums are scanned by kernels of their own (1/64 of the
+// elements: three short launches instead of two passes over 34 MB), a wave of k_dec_assemble scans its 64 records itself.
 __global__ __launch_bounds__(256) void k_dec_sizes(const uint8_t *arena, DecInfo *info, const DecBlock *blocks, const uint32_t *offs,
-                                                   uint32_t ostride, uint32_t *cols, uint32_t cstride, unsigned long long *btot)
+                                                   uint32_t ostride, uint32_t *cols, uint32_t cstride, unsigned long long *btot, uint32_t *gsum, uint32_t gstride)
 {
     uint32_t n_rec = info->n_rec, nb = info->n_blocks;
     if (info->status) return;
@@ -1693,6 +1697,13 @@ __global__ __launch_bounds__(256) void k_dec_sizes(const uint8_t *arena, DecInfo
                 cols[2 * (size_t)cstride + r] = (uint32_t)v2;
             }
         }
+        { // the group's sums (a wave's 64 records are one group: r0 is a multiple of 256)
+            uint32_t g0 = (uint32_t)v0, g1 = (uint32_t)v1, g2 = (uint32_t)v2;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { g0 += __shfl_xor(g0, d, WAVE); g1 += __shfl_xor(g1, d, WAVE); g2 += __shfl_xor(g2, d, WAVE); }
+            const uint32_t rw = r0 + (threadIdx.x & ~63u);
+            if (lane == 0 && rw < r_end) { gsum[rw >> 6] = g0; gsum[gstride + (rw >> 6)] = g1; gsum[2 * (size_t)gstride + (rw >> 6)] = g2; }
+        }
         // the wave's records share a block almost always; a wave that straddles two blocks adds its lanes one by one
         const unsigned long long act = __ballot(bi != 0xFFFFFFFFu);
         if (!act) continue;
@@ -1724,7 +1735,10 @@ __global__ __launch_bounds__(256) void k_dec_sizes(const uint8_t *arena, DecInfo
 }
 
 // one workgroup: the 64-bit totals of every block against its stream lengths, their sum against the output capacity
-__global__ __launch_bounds__(256) void k_dec_check(DecInfo *info, const DecBlock *blocks, const unsigned long long *btot, size_t out_cap)
+// ... and, per block, the scanned value of the packed-bases and quality columns at its first record (bbase[c][b]: the streams of a
+// block start at its own arena offset): the scanned sum of its group plus the records of that group in front of it
+__global__ __launch_bounds__(256) void k_dec_check(DecInfo *info, const DecBlock *blocks, const unsigned long long *btot, size_t out_cap, const uint32_t *cols,
+                                                   uint32_t cstride, const uint32_t *gsum, uint32_t gstride, uint32_t *bbase, uint32_t bstride)
 {
     __shared__ unsigned long long s_sum[256];
     if (info->status) return;
@@ -1732,6 +1746,12 @@ __global__ __launch_bounds__(256) void k_dec_check(DecInfo *info, const DecBlock
     unsigned long long mine = 0;
     for (uint32_t b = threadIdx.x; b < nb; b += 256) {
         const DecBlock *k = &blocks[b];
+        {
+            const uint32_t r0 = k->rec_base, g0 = r0 >> 6;
+            uint32_t b0 = gsum[g0], b1 = gsum[gstride + g0];
+            for (uint32_t r = g0 << 6; r < r0; r++) { b0 += cols[r]; b1 += cols[cstride + r]; }
+            bbase[b] = b0; bbase[bstride + b] = b1;
+        }
         if (btot[3ull * b] > k->raw_len[S_SEQ]) dec_fail(info, FQZ_E_TRUNC_SEQ);
         if (btot[3ull * b + 1] > k->raw_len[S_QUAL]) dec_fail(info, FQZ_E_TRUNC_QUAL);
         mine += btot[3ull * b + 2];
@@ -1771,8 +1791,10 @@ __global__ __launch_bounds__(256) void k_dec_check(DecInfo *info, const DecBlock
 #define DSH(v, i) ((uint32_t)__shfl((int)(v), (int)(i), WAVE))
 __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict__ arena, DecInfo *info, const DecBlock *__restrict__ blocks,
                                                       const uint32_t *__restrict__ offs, uint32_t ostride, const uint32_t *__restrict__ cols,
-                                                      uint32_t cstride, uint32_t qoff, uint8_t *__restrict__ out)
+                                                      uint32_t cstride, uint32_t qoff, uint8_t *__restrict__ out, const uint32_t *__restrict__ gsum,
+                                                      uint32_t gstride, const uint32_t *__restrict__ bbase, uint32_t bstride)
 {
+    static_assert(ASM_G == 64, "a wave's records are one group of the scanned sums");
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][ASM_W + 32];
     if (info->status) return;
     const uint32_t n_rec = info->n_rec, nb = info->n_blocks;
@@ -1784,18 +1806,23 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *__restrict_
         const uint32_t r = lane < ASM_G ? g * ASM_G + lane : n_rec;
         uint32_t m_L = 0, m_hdr = 0, m_H = 0, m_seq = 0, m_np = 0, m_nn = 0, m_plus = 0, m_P = 0, m_q = 0;
         size_t m_out = 0;
+        // the record's places in the packed bases, the qualities and the text: the scanned sums of its group + a wave scan of the sizes
+        uint32_t v0 = 0, v1 = 0, v2 = 0;
+        if (r < n_rec) { v0 = cols[r]; v1 = cols[cstride + r]; v2 = cols[2 * (size_t)cstride + r]; }
+        const uint32_t e0 = gsum[g] + wave_incl_scan(v0) - v0, e1 = gsum[gstride + g] + wave_incl_scan(v1) - v1;
+        const uint32_t e2 = gsum[2 * (size_t)gstride + g] + wave_incl_scan(v2) - v2;
         if (r < n_rec) {
-            const DecBlock *b = &blocks[find_block(blocks, nb, r)];
-            const uint32_t r0 = b->rec_base;
-            m_L = cols[cstride + r + 1] - cols[cstride + r];
-            m_out = cols[2 * (size_t)cstride + r];
+            const uint32_t bi = find_block(blocks, nb, r);
+            const DecBlock *b = &blocks[bi];
+            m_L = v1;
+            m_out = e2;
             m_hdr = b->a_off[S_HDR] + offs[r];
             m_H = rd16(arena + m_hdr);
-            m_seq = b->a_off[S_SEQ] + (cols[r] - cols[r0]);
+            m_seq = b->a_off[S_SEQ] + (e0 - bbase[bi]);
             m_np = b->a_off[S_NPOS] + offs[2 * (size_t)ostride + r];
             m_nn = rd16(arena + m_np);
             if (b->raw_len[S_PLUS]) { m_plus = b->a_off[S_PLUS] + offs[ostride + r]; m_P = rd16(arena + m_plus); }
-            m_q = b->a_off[S_QUAL] + (cols[cstride + r] - cols[cstride + r0]);
+            m_q = b->a_off[S_QUAL] + (e1 - bbase[bstride + bi]);
         }
         const uint32_t o32 = (uint32_t)m_out; // a batch decodes to < 4 GiB (checked on the host before the launch)
         const uint32_t rec_end = o32 + (r < n_rec ? m_H + m_P + 2 * m_L + 6 : 0u);
@@ -2201,7 +2228,8 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     if ((rc = d.frames.ensure((sizeof(DecFrame) + sizeof(uint2)) * ((size_t)n_frames + 1)))) return rc; // frames | groups with rANS blocks
     DecFrame *dfr = d.frames.as<DecFrame>();
     uint2 *rlist = version == FQZ_VERSION3 ? (uint2 *)(dfr + (size_t)n_frames + 1) : nullptr; // (version-3 files only: FQZ-R1, fqz_rans.h)
-    if ((rc = d.rec.ensure(4ull * (3ull * ostride + 3ull * cstride) + 64))) return rc;
+    const uint32_t n_groups = (n_rec + 63) / 64, gstride = n_groups + 2, bstride = nb + 1;
+    if ((rc = d.rec.ensure(4ull * (3ull * ostride + 3ull * cstride + 3ull * gstride + 2ull * bstride) + 64))) return rc;
     uint32_t pmax = n_rec / DSCAN_TILE + 2;
     if ((rc = d.partials.ensure(4ull * 3 * pmax + 24ull * ((size_t)nb + 1)))) return rc;
     if ((rc = d.tables.ensure(((size_t)n_tiles + 1) * (WALK_ENTRIES * sizeof(WalkF) + sizeof(WalkEntry))))) return rc;
@@ -2210,6 +2238,7 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     DecChunk *dch = d.chunks.as<DecChunk>();
     uint8_t *darena = d.streams.as<uint8_t>();
     uint32_t *offs = d.rec.as<uint32_t>(), *cols = offs + 3ull * ostride, *partials = d.partials.as<uint32_t>();
+    uint32_t *gsum = cols + 3ull * cstride, *bbase = gsum + 3ull * gstride; // sums per 64 records (scanned in place), column values at the blocks' first records
     unsigned long long *btot = (unsigned long long *)(partials + ((3ull * pmax + 1) & ~1ull)); // 64-bit column totals per block
     HIP_TRY(hipMemsetAsync(btot, 0, 24ull * nb, st));
     HIP_TRY(hipMemcpyAsync(blocks, hb, sizeof(DecBlock) * (size_t)nb, hipMemcpyHostToDevice, st));
@@ -2318,23 +2347,23 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     if (n_rec) {
         uint32_t g = (n_rec + 1023) / 1024; // (runs of >= 1024 records: one flush of the block totals per workgroup)
         if (g > 2048) g = 2048;
-        PROF(ctx, st, "k_dec_sizes", hipLaunchKernelGGL(k_dec_sizes, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride, btot));
+        PROF(ctx, st, "k_dec_sizes", hipLaunchKernelGGL(k_dec_sizes, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride, btot, gsum, gstride));
     }
     {
-        uint32_t nwg = (n_rec + DSCAN_TILE - 1) / DSCAN_TILE;
+        uint32_t nwg = (n_groups + DSCAN_TILE - 1) / DSCAN_TILE; // (the scans run over the group sums)
         if (!nwg) nwg = 1;
-        hipLaunchKernelGGL(k_dscan_reduce, dim3(nwg, 3), dim3(256), 0, st, cols, &info->n_rec, cstride, partials, pmax);
-        hipLaunchKernelGGL(k_dscan_top, dim3(3), dim3(256), 0, st, cols, &info->n_rec, cstride, partials, pmax);
-        hipLaunchKernelGGL(k_dscan_apply, dim3(nwg, 3), dim3(256), 0, st, cols, &info->n_rec, cstride, partials, pmax);
+        hipLaunchKernelGGL(k_dscan_reduce, dim3(nwg, 3), dim3(256), 0, st, gsum, &info->n_groups, gstride, partials, pmax);
+        hipLaunchKernelGGL(k_dscan_top, dim3(3), dim3(256), 0, st, gsum, &info->n_groups, gstride, partials, pmax);
+        hipLaunchKernelGGL(k_dscan_apply, dim3(nwg, 3), dim3(256), 0, st, gsum, &info->n_groups, gstride, partials, pmax);
     }
-    PROF(ctx, st, "k_dec_check", hipLaunchKernelGGL(k_dec_check, dim3(1), dim3(256), 0, st, info, blocks, btot, out_cap));
+    PROF(ctx, st, "k_dec_check", hipLaunchKernelGGL(k_dec_check, dim3(1), dim3(256), 0, st, info, blocks, btot, out_cap, cols, cstride, gsum, gstride, bbase, bstride));
     if (n_rec) {
         uint32_t g = ((n_rec + ASM_G - 1) / ASM_G + 3) / 4;
         if (g > 8192) g = 8192;
         if (!g) g = 1;
         uint32_t qoff = qual_encoding == FQZ_ENCODING_PHRED64 ? 64u : 33u;
         if (forked) { HIP_TRY(hipStreamWaitEvent(st, d.ev_join, 0)); HIP_TRY(hipStreamWaitEvent(st, d.ev_seq, 0)); forked = false; }
-        if (!skip_assemble) PROF(ctx, st, "k_dec_assemble", hipLaunchKernelGGL(k_dec_assemble, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride, qoff, d_out));
+        if (!skip_assemble) PROF(ctx, st, "k_dec_assemble", hipLaunchKernelGGL(k_dec_assemble, dim3(g), dim3(256), 0, st, darena, info, blocks, offs, ostride, cols, cstride, qoff, d_out, gsum, gstride, bbase, bstride));
     }
     if (forked) { HIP_TRY(hipStreamWaitEvent(st, d.ev_join, 0)); HIP_TRY(hipStreamWaitEvent(st, d.ev_seq, 0)); } // (no records: nothing assembled, still join)
     if (n_chunks) HIP_TRY(hipStreamWaitEvent(st, d.ev_joinx, 0)); // the checksums: before the status is read

@@ -73,7 +73,7 @@ struct DecInfo {
     unsigned long long stream_raw[FQZ_NS];
     unsigned long long stream_comp[FQZ_NS];
     uint32_t n_rgroups;     // groups with rANS blocks (version-3 files; appended by k_dec_index)
-    uint32_t pad_;
+    uint32_t n_groups;      // groups of 64 records (k_dec_sizes sums them, the scans run over the groups, k_dec_assemble scans inside one)
 };
 
 #define HIP_TRY(expr)                                   \
