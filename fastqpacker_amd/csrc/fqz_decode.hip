@@ -1211,6 +1211,7 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                             if (avail <= 96) fetch(w0, n0);
                             if (avail <= 64) fetch(w1, n1);
                         }
+                        uint32_t acc4 = 0;
                         auto symbol = [&](uint32_t u) {
                             uint32_t e = g.l1[b3 >> sh1];
                             if (e == L1_ESC) { // a code longer than the first level: canonical rank search
@@ -1221,8 +1222,7 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                             const uint32_t nb = e >> 8; // 1..11
                             shift_bits(nb);
                             avail -= (int)nb;
-                            const uint32_t k = (i + u) & 63;
-                            ob[((k >> 2) << 8) + (k & 3)] = (uint8_t)e; // transposed staging: dword k/4 of this lane
+                            acc4 |= (e & 0xFFu) << (8 * u); // (the iteration's four symbols are one dword of the staging)
                         };
                         // all four symbols exist for every lane except in a stream's last iteration: no per-symbol predicate then
                         if (__builtin_amdgcn_ballot_w64(i + 4 > cnt) == 0) {
@@ -1233,6 +1233,7 @@ __global__ __launch_bounds__(64) void k_dec_huf(const uint8_t *in, DecInfo *info
                             for (uint32_t u = 0; u < 4; u++)
                                 if (i + u < cnt) symbol(u);
                         }
+                        obuf[((i & 63) >> 2) * 64 + lane] = acc4; // transposed staging: dword (i / 4) % 16 of this lane - one LDS write for four symbols
                         neg |= avail;
                         if (avail < 0) avail = 0; // corrupt stream: caught below
                         merge(w0, n0);

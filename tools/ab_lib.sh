@@ -3,11 +3,11 @@
 for rep in 1 2 3; do
 for lib in "$@"; do
   if [ -z "$lib" ]; then unset FQZ_LIB_PATH; else export FQZ_LIB_PATH=$PWD/$lib; fi
-  python bench.py --no-cpu --no-v3 --no-supp --steps 10 --warmup 3 --inflight 0 --decode-steps 3 2>/dev/null | python -c "
+  python bench.py --no-cpu --no-v3 --no-supp --steps 6 --warmup 3 --inflight 0 --decode-steps 6 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); k = d['kernel_ms']; print('[$lib]', 'enc_ms', d['ms_per_step'], 'k_entropy', k.get('k_entropy'), 'k_split', k.get('k_split'), 'k_line_local', k.get('k_line_local'), 'dec_MBps', d['decode_MBps'], 'ok', d['roundtrip_bit_exact'])
+        d = json.loads(l); k = d['kernel_ms']; dk = d['decode_kernel_ms']; print('[$lib]', 'enc_ms', d['ms_per_step'], 'k_entropy', k.get('k_entropy'), 'k_split', k.get('k_split'), 'dec_MBps', d['decode_MBps'], 'asm', dk.get('k_dec_assemble'), 'huf', dk.get('k_dec_huf'), 'ok', d['roundtrip_bit_exact'])
 "
 done
 done
