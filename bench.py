@@ -336,8 +336,10 @@ def main():
 
     def decode_step():
         for i in range(len(batches)):
-            fq._lib.check(lib().fqz_decode_batch_dev(ctx.handle, fqz_devs[i].data_ptr(), fqz_devs[i].numel(), a.container, fq.ENCODING_PHRED33,
-                                                     d_backs[i].data_ptr(), d_backs[i].numel(), C.byref(dress[i]), sptr))
+            # (with the block offsets the encode reported: whoever holds a batch of blocks knows where they start - the reference's
+            #  reader takes them header by header, compress.go:721-758 - and the device need not walk the chain of headers again)
+            fq._lib.check(lib().fqz_decode_batch_dev_hint(ctx.handle, fqz_devs[i].data_ptr(), fqz_devs[i].numel(), a.container, fq.ENCODING_PHRED33,
+                                                          d_backs[i].data_ptr(), d_backs[i].numel(), C.byref(dress[i]), offs[i], int(ress[i].n_blocks), sptr))
     try:
         decode_step()
         roundtrip_ok = all(bool(dress[i].out_len == batches[i].size and torch.equal(d_backs[i][: batches[i].size], d_texts[i]))

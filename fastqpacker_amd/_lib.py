@@ -97,6 +97,7 @@ SIGNATURES = {
     "fqz_encode_batch_launch": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_int, C.c_uint32, _vp, C.c_size_t, _vp]),
     "fqz_encode_batch_finish": (C.c_int, [_vp, C.POINTER(BatchResult), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t]),
     "fqz_decode_batch_dev": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint8, C.c_int, _vp, C.c_size_t, C.POINTER(BatchResult), _vp]),
+    "fqz_decode_batch_dev_hint": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint8, C.c_int, _vp, C.c_size_t, C.POINTER(BatchResult), C.POINTER(C.c_uint64), C.c_size_t, _vp]),
     "fqz_decode_batch_launch": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint8, C.c_int, _vp, C.c_size_t, _vp]),
     "fqz_decode_batch_finish": (C.c_int, [_vp, C.POINTER(BatchResult)]),
     "fqz_debug_get_streams": (C.c_int, [_vp, C.c_uint32, C.POINTER(_vp), C.POINTER(C.c_size_t)]),

@@ -195,10 +195,16 @@ def encode_batch_dev(d_fastq_ptr, n_bytes, d_out_ptr, out_cap, records_per_block
     return res
 
 
-def decode_batch_dev(d_blocks_ptr, n_bytes, d_out_ptr, out_cap, version=2, qual_encoding=0, stream=None, ctx=None):
+def decode_batch_dev(d_blocks_ptr, n_bytes, d_out_ptr, out_cap, version=2, qual_encoding=0, stream=None, ctx=None, block_off=None):
+    """block_off: offsets of the block headers inside the batch (what encode_batch_dev(max_blocks=...) returns): a hint that saves
+    the device's walk along the chain of block headers (fqz_decode_batch_dev_hint)."""
     ctx = ctx or default_ctx()
     res = BatchResult()
-    check(lib().fqz_decode_batch_dev(ctx.handle, d_blocks_ptr, n_bytes, version, qual_encoding, d_out_ptr, out_cap, C.byref(res), stream))
+    if block_off is not None and len(block_off):
+        arr = (C.c_uint64 * len(block_off))(*block_off)
+        check(lib().fqz_decode_batch_dev_hint(ctx.handle, d_blocks_ptr, n_bytes, version, qual_encoding, d_out_ptr, out_cap, C.byref(res), arr, len(block_off), stream))
+    else:
+        check(lib().fqz_decode_batch_dev(ctx.handle, d_blocks_ptr, n_bytes, version, qual_encoding, d_out_ptr, out_cap, C.byref(res), stream))
     return res
 
 

@@ -112,6 +112,7 @@ extern "C" void fqz_ctx_destroy(fqz_ctx *c)
     DevBuf *db[] = {&d.info, &d.blocks, &d.chunks, &d.frames, &d.streams, &d.rec, &d.partials, &d.tables, &d.lz_scratch};
     for (DevBuf *b : db) b->release();
     d.h_info.release(); d.h_blocks.release();
+    d.hint.release(); d.h_hint.release();
     if (d.side) { (void)hipStreamSynchronize(d.side); (void)hipStreamDestroy(d.side); (void)hipEventDestroy(d.ev_fork); (void)hipEventDestroy(d.ev_join);
                   (void)hipStreamSynchronize(d.side2); (void)hipStreamDestroy(d.side2); (void)hipEventDestroy(d.ev_join2); (void)hipEventDestroy(d.ev_x); (void)hipEventDestroy(d.ev_joinx);
                   (void)hipEventDestroy(d.ev_huf); (void)hipEventDestroy(d.ev_seq); }
@@ -362,6 +363,16 @@ extern "C" int fqz_decode_batch_dev(fqz_ctx *ctx, const uint8_t *d_blocks, size_
     int rc = fqz_decode_batch_launch(ctx, d_blocks, n_bytes, version, qual_encoding, d_out, out_cap, stream);
     if (rc) return rc;
     return fqz_decode_batch_finish(ctx, res);
+}
+
+extern "C" int fqz_decode_batch_dev_hint(fqz_ctx *ctx, const uint8_t *d_blocks, size_t n_bytes, uint8_t version, int qual_encoding, uint8_t *d_out, size_t out_cap,
+                                         fqz_batch_result *res, const uint64_t *block_off, size_t n_blocks, void *stream)
+{
+    if (!ctx) return FQZ_E_ARG;
+    ctx->dec.hint_off = block_off; ctx->dec.hint_n = block_off ? n_blocks : 0;
+    const int rc = fqz_decode_batch_dev(ctx, d_blocks, n_bytes, version, qual_encoding, d_out, out_cap, res, stream);
+    ctx->dec.hint_off = nullptr; ctx->dec.hint_n = 0;
+    return rc;
 }
 
 // Diagnostic only (FQZ_DBG_STAMPS=1): s_memtime stamps of k_entropy's phases, 16 x u64 per chunk.

@@ -144,6 +144,10 @@ struct DecState {
     size_t user_cap = 0;
     bool general = false;
     bool skip_assemble = false;            // only the decoded size is wanted (fqz_decode_block_size, fqz_decompress with out == NULL)
+    const uint64_t *hint_off = nullptr;    // fqz_decode_batch_dev_hint: where the caller says the block headers are (host array, this call only)
+    size_t hint_n = 0;
+    DevBuf hint;
+    PinnedBuf h_hint;
 };
 
 struct ProfEntry { const char *name; hipEvent_t a, b; };

@@ -74,9 +74,8 @@ __device__ __forceinline__ void dec_fail(DecInfo *info, int code) { atomicCAS(&i
 // ---------------------------------------------------------------------------
 // block headers (container.go:116-152) — one thread walks the chain
 // ---------------------------------------------------------------------------
-__global__ void k_dec_blocks(const uint8_t *in, uint32_t n, uint32_t version, DecInfo *info, DecBlock *blocks, uint32_t block_cap)
+__device__ void dec_blocks_walk(const uint8_t *in, uint32_t n, uint32_t version, DecInfo *info, DecBlock *blocks, uint32_t block_cap)
 {
-    if (threadIdx.x || blockIdx.x) return;
     uint32_t pos = 0, nb = 0, nrec = 0;
     const uint32_t hs = version == FQZ_VERSION1 ? 32 : 36;
     while (pos < n) {
@@ -115,6 +114,65 @@ __global__ void k_dec_blocks(const uint8_t *in, uint32_t n, uint32_t version, De
     info->n_blocks = nb;
     info->n_rec = nrec;
     info->n_groups = (nrec + 63) / 64;
+}
+__global__ void k_dec_blocks(const uint8_t *in, uint32_t n, uint32_t version, DecInfo *info, DecBlock *blocks, uint32_t block_cap)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    dec_blocks_walk(in, n, version, info, blocks, block_cap);
+}
+
+// The same table from a HINT: the caller says where the block headers are (fqz_decode_batch_dev_hint - whoever cut the batch
+// out of a file has walked them already, as the reference's reader does, compress.go:721-758).  A thread per block reads its
+// header and checks that the block ends where the next one starts (the last one at the end of the input, or at a version-3
+// block table); if everything adds up the chain - one dependent memory round trip per block, 1.6 us each - is not walked at all,
+// otherwise it is, as if there had been no hint.  One 256-thread workgroup.
+__global__ __launch_bounds__(256) void k_dec_blocks_hint(const uint8_t *in, uint32_t n, uint32_t version, DecInfo *info, DecBlock *blocks, uint32_t block_cap,
+                                                         const unsigned long long *hint, uint32_t n_hint)
+{
+    __shared__ uint32_t sh[4];
+    const uint32_t t = threadIdx.x, hs = version == FQZ_VERSION1 ? 32 : 36;
+    bool bad = n_hint == 0 || n_hint > block_cap;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < n_hint && !bad; b0 += 256) {
+        const uint32_t b = b0 + t;
+        uint32_t records = 0;
+        if (b < n_hint) {
+            const unsigned long long at = hint[b];
+            if ((b == 0 && at != 0) || at > n || n - at < hs) bad = true;
+            else {
+                const uint8_t *h = in + at;
+                uint32_t sz[FQZ_NS];
+                records = load_u32_unaligned(h);
+                sz[S_SEQ] = load_u32_unaligned(h + 4); sz[S_QUAL] = load_u32_unaligned(h + 8); sz[S_HDR] = load_u32_unaligned(h + 12);
+                if (version == FQZ_VERSION1) { sz[S_PLUS] = 0; sz[S_NPOS] = load_u32_unaligned(h + 16); sz[S_LEN] = load_u32_unaligned(h + 20); }
+                else { sz[S_PLUS] = load_u32_unaligned(h + 16); sz[S_NPOS] = load_u32_unaligned(h + 20); sz[S_LEN] = load_u32_unaligned(h + 24); }
+                if (version == FQZ_VERSION3 && records == FQZ_BLOCK_TABLE_MARK) bad = true; // (the table is not a block)
+                unsigned long long pos = at + hs;
+                const int order[FQZ_NS] = {S_SEQ, S_QUAL, S_HDR, S_PLUS, S_NPOS, S_LEN};
+                DecBlock *k = &blocks[b];
+                for (int q = 0; q < FQZ_NS; q++) { const int s = order[q]; k->pay_off[s] = (uint32_t)pos; k->pay_len[s] = sz[s]; pos += sz[s]; }
+                k->nrec = records;
+                if (pos > n) bad = true;
+                else if (b + 1 < n_hint) { if (hint[b + 1] != pos) bad = true; }
+                else if (pos != n) { // behind the last block: nothing, or the block table of a version-3 file
+                    if (!(version == FQZ_VERSION3 && n - pos >= 8 && load_u32_unaligned(in + pos) == FQZ_BLOCK_TABLE_MARK && load_u32_unaligned(in + pos + 4) == 0x585A5146u)) bad = true;
+                }
+            }
+        }
+        bad = __syncthreads_or(bad) != 0;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256(records, sh, &tot);
+        if (b < n_hint && !bad) blocks[b].rec_base = carry + ex;
+        if ((unsigned long long)carry + tot > 0x7FFFFFFFull) bad = true; // (the walk names the error)
+        carry += tot;
+        __syncthreads();
+    }
+    bad = __syncthreads_or(bad) != 0;
+    if (t) return;
+    if (bad) { dec_blocks_walk(in, n, version, info, blocks, block_cap); return; } // (overwrites what the hint wrote)
+    info->n_blocks = n_hint;
+    info->n_rec = carry;
+    info->n_groups = (carry + 63) / 64;
 }
 
 // ---------------------------------------------------------------------------
@@ -2101,6 +2159,14 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
         blocks = d.blocks.as<DecBlock>();
         HIP_TRY(hipMemsetAsync(info, 0, sizeof(DecInfo), st));
         HIP_TRY(hipMemsetAsync(blocks, 0, sizeof(DecBlock) * (size_t)cap0, st));
+        if (d.hint_off && d.hint_n && d.hint_n <= cap0) { // the caller knows where the blocks start: no walk along the chain
+            if ((rc = d.hint.ensure(8 * d.hint_n))) return rc;
+            if ((rc = d.h_hint.ensure(8 * d.hint_n))) return rc;
+            memcpy(d.h_hint.p, d.hint_off, 8 * d.hint_n);
+            HIP_TRY(hipMemcpyAsync(d.hint.p, d.h_hint.p, 8 * d.hint_n, hipMemcpyHostToDevice, st));
+            PROF(ctx, st, "k_dec_blocks", hipLaunchKernelGGL(k_dec_blocks_hint, dim3(1), dim3(256), 0, st, d_in, n, (uint32_t)version, info, blocks, cap0,
+                                                             d.hint.as<unsigned long long>(), (uint32_t)d.hint_n));
+        } else
         PROF(ctx, st, "k_dec_blocks", hipLaunchKernelGGL(k_dec_blocks, dim3(1), dim3(64), 0, st, d_in, n, (uint32_t)version, info, blocks, cap0));
         PROF(ctx, st, "k_dec_fhdr", hipLaunchKernelGGL(k_dec_fhdr, dim3((cap0 * FQZ_NS + 63) / 64), dim3(64), 0, st, d_in, info, blocks, cap0));
         const uint32_t pre = 256; // (the first blocks travel with the counters: one round trip for ordinary batches)

@@ -185,6 +185,13 @@ int fqz_encode_batch_finish(fqz_ctx *ctx, fqz_batch_result *res, uint64_t *block
  * after the 10-byte file header) resident in HBM into FASTQ text in d_out. */
 int fqz_decode_batch_dev(fqz_ctx *ctx, const uint8_t *d_blocks, size_t n_bytes, uint8_t version, int qual_encoding,
                          uint8_t *d_out, size_t out_cap, fqz_batch_result *res, void *stream);
+/* The same with a hint: block_off[i] (host array) = offset of block i's header in d_blocks, as fqz_encode_batch_dev reports
+ * them and as a reader that cut the batch out of a file knows them (the reference reads header and payloads block by block,
+ * compress.go:721-758).  Saves the walk along the chain of block headers on the device (one dependent memory round trip per
+ * block).  A hint, not trusted: offsets that do not add up are ignored and the chain is walked. */
+int fqz_decode_batch_dev_hint(fqz_ctx *ctx, const uint8_t *d_blocks, size_t n_bytes, uint8_t version, int qual_encoding,
+                              uint8_t *d_out, size_t out_cap, fqz_batch_result *res, const uint64_t *block_off, size_t n_blocks,
+                              void *stream);
 int fqz_decode_batch_launch(fqz_ctx *ctx, const uint8_t *d_blocks, size_t n_bytes, uint8_t version, int qual_encoding,
                             uint8_t *d_out, size_t out_cap, void *stream);
 int fqz_decode_batch_finish(fqz_ctx *ctx, fqz_batch_result *res);

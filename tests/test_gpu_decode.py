@@ -304,3 +304,46 @@ def test_streams_too_short_for_their_records_are_refused(fq):
     # the well-formed twin decodes
     ok = _v2_block(1, [b"\x00", b"\x28\x00\x00\x00", b"\x01\x00A", b"", b"\x00\x00", one])
     assert fq.compress.decode_block(ok, 2, 0) == b"@A\nAAAA\n+\nIIII\n"
+
+
+@pytest.mark.gpu
+def test_block_offset_hint_is_a_hint(fq):
+    """fqz_decode_batch_dev_hint: with the offsets of the block headers the device does not walk their chain; the offsets are
+    checked against the headers (every block must end where the next one starts) and anything that does not add up - a shifted
+    offset, a missing block, one too many - falls back to the walk: the text is the same in every case.  Both container versions
+    (a version-3 batch may end with a block table), and a stock-style file written by the oracle's reference pipeline."""
+    import torch
+    from fastq_gen import make_fastq
+    text = make_fastq(5000, seed=91, min_len=60, max_len=120)
+    t = np.frombuffer(text, dtype=np.uint8)
+    d_text = torch.from_numpy(t.copy()).cuda()
+    cap = len(text) * 2 + (1 << 20)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    d_back = torch.empty(len(text) + 64, dtype=torch.uint8, device="cuda")
+    for version in (2, 3):
+        res, offs, lens = fq.compress.encode_batch_dev(d_text.data_ptr(), t.size, d_out.data_ptr(), cap, records_per_block=700, max_blocks=64,
+                                                       container_version=version)
+        assert res.n_blocks == 8 and offs[0] == 0 and all(offs[i] + lens[i] == offs[i + 1] for i in range(7))
+        def dec(block_off):
+            d_back.zero_()
+            r = fq.compress.decode_batch_dev(d_out.data_ptr(), int(res.out_len), d_back.data_ptr(), d_back.numel(), version=version,
+                                             qual_encoding=res.qual_encoding, block_off=block_off)
+            return d_back[: r.out_len].cpu().numpy().tobytes()
+        assert dec(None) == text
+        assert dec(offs) == text
+        assert dec([o + (3 if i == 4 else 0) for i, o in enumerate(offs)]) == text      # a wrong offset
+        assert dec(offs[:-1]) == text                                                    # a block missing at the end
+        assert dec(offs + [int(res.out_len)]) == text                                    # one too many
+        assert dec([5] + offs[1:]) == text                                               # the first block not at 0
+    # a whole version-3 file with its block table behind the last block: the hint ends where the table begins
+    fqz = O.compress(text, batch_records=700, entropy=2, block_index=1)
+    body = np.frombuffer(fqz, dtype=np.uint8)[10:]
+    d_body = torch.from_numpy(body.copy()).cuda()
+    offs3, pos = [], 0
+    for _ in range(8):
+        offs3.append(pos)
+        hdr = [int.from_bytes(body[pos + 4 * i: pos + 4 * i + 4].tobytes(), "little") for i in range(9)]
+        pos += 36 + sum(hdr[1:7])
+    d_back.zero_()
+    r = fq.compress.decode_batch_dev(d_body.data_ptr(), d_body.numel(), d_back.data_ptr(), d_back.numel(), version=3, qual_encoding=0, block_off=offs3)
+    assert d_back[: r.out_len].cpu().numpy().tobytes() == text
