@@ -349,11 +349,18 @@ struct FrameWalk {
 
 // rlist (version-3 files, else nullptr): the walk announces the rANS groups it finds to k_dec_rans, as k_dec_index does for indexed payloads
 __global__ __launch_bounds__(FRAME_NT) void k_dec_frames(const uint8_t *in, uint32_t in_bytes, DecInfo *info, DecBlock *blocks, DecChunk *chunks, DecFrame *frames, int pass,
-                                                         int v3, uint2 *rlist, uint32_t rcap)
+                                                         int v3, uint2 *rlist, uint32_t rcap, uint32_t set_chunks = 0xFFFFFFFFu,
+                                                         unsigned long long *zero = nullptr, uint32_t n_zero = 0)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[2][FRAME_BUF];
     __shared__ FrameWalk W;
     const uint32_t id = blockIdx.x, t = threadIdx.x;
+    // (two chores of the launch that would be a copy and a fill of their own - ~8 us of queue time each between the host's
+    //  read-back and the first bulk kernel: the chunk count the host worked out, and the block totals k_dec_sizes adds into)
+    if (id == 0) {
+        if (t == 0 && set_chunks != 0xFFFFFFFFu) info->n_chunks = set_chunks;
+        for (uint32_t i = t; i < n_zero; i += FRAME_NT) zero[i] = 0;
+    }
     const uint32_t nb = info->n_blocks;
     if (id >= nb * FQZ_NS || info->status) return;
     DecBlock *b = &blocks[id / FQZ_NS];
@@ -2309,12 +2316,11 @@ static int dec_launch(fqz_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t
     uint32_t *offs = d.rec.as<uint32_t>(), *cols = offs + 3ull * ostride, *partials = d.partials.as<uint32_t>();
     uint32_t *gsum = cols + 3ull * cstride, *bbase = gsum + 3ull * gstride; // sums per 64 records (scanned in place), column values at the blocks' first records
     unsigned long long *btot = (unsigned long long *)(partials + ((3ull * pmax + 1) & ~1ull)); // 64-bit column totals per block
-    HIP_TRY(hipMemsetAsync(btot, 0, 24ull * nb, st));
     HIP_TRY(hipMemcpyAsync(blocks, hb, sizeof(DecBlock) * (size_t)nb, hipMemcpyHostToDevice, st));
     hi->n_chunks = n_chunks;
-    HIP_TRY(hipMemcpyAsync(&info->n_chunks, &hi->n_chunks, 4, hipMemcpyHostToDevice, st));
-    // ---- bulk kernels
-    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, dch, dfr, general ? 1 : 2, version == FQZ_VERSION3 ? 1 : 0, rlist, n_frames));
+    // ---- bulk kernels (the first one also sets info->n_chunks and clears the block totals)
+    PROF(ctx, st, "k_dec_frames", hipLaunchKernelGGL(k_dec_frames, dim3(fgrid), dim3(FRAME_NT), 0, st, d_in, n, info, blocks, dch, dfr, general ? 1 : 2, version == FQZ_VERSION3 ? 1 : 0, rlist, n_frames,
+                                                     n_chunks, btot, 3u * nb));
     if (any_indexed) PROF(ctx, st, "k_dec_index", hipLaunchKernelGGL(k_dec_index, dim3(fgrid), dim3(256), 0, st, d_in, info, blocks, dch, dfr, rlist, n_frames));
     // The record walks and the size scans below need only the header / plus / nPos / lengths streams, the text assembly
     // at the end needs the bases and qualities too.  The latter are 3/4 of the entropy decode and the walks leave the

@@ -207,7 +207,11 @@ static int compress_job(fqz_ctx *ctx, Io &io, const fqz_options *opts, const Sha
             size_t n = 0;
             if (io.mem_in || !io.rd) { // memory source: straight over the link
                 const size_t nd = io.dev_in_n - io.dev_in_pos < slice ? io.dev_in_n - io.dev_in_pos : slice; // resident part first
-                if (nd && hipMemcpy(s.d_new.p, io.dev_in + io.dev_in_pos, nd, hipMemcpyDeviceToDevice) != hipSuccess) { P.fail(FQZ_E_HIP); return; }
+                // (a device-to-device hipMemcpy may return before the copy has run; the batch is put together on the lane's own stream,
+                //  which does not wait for the null stream: the copy is made on this thread's stream and waited for.  Without the wait a
+                //  shard of fqz_compress_multi now and then read its slice half copied - a parse error once in a few hundred runs)
+                if (nd && (hipMemcpyAsync(s.d_new.p, io.dev_in + io.dev_in_pos, nd, hipMemcpyDeviceToDevice, hipStreamPerThread) != hipSuccess ||
+                           hipStreamSynchronize(hipStreamPerThread) != hipSuccess)) { P.fail(FQZ_E_HIP); return; }
                 io.dev_in_pos += nd;
                 const size_t nh = io.mem_in_n - io.mem_in_pos < slice - nd ? io.mem_in_n - io.mem_in_pos : slice - nd;
                 if (nh && hipMemcpy(s.d_new.as<uint8_t>() + nd, io.mem_in + io.mem_in_pos, nh, hipMemcpyHostToDevice) != hipSuccess) { P.fail(FQZ_E_HIP); return; }
