@@ -73,6 +73,7 @@ struct Slot {
     Slot(DevBuf &a, PinnedBuf &b, PinnedBuf &c) : d_new(a), h_in(b), h_out(c) {}
     size_t n_new = 0;
     bool eof = false;
+    std::vector<uint64_t> boff; // decompression: where the feeder found the block headers of the slice (a hint for the device, fqz_dec_launch)
     // filled by the calling thread for the drainer
     const uint8_t *d_res = nullptr;
     size_t res_len = 0;
@@ -353,6 +354,7 @@ static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *op
                 const uint8_t *p = io.mem_in + io.mem_in_pos;
                 const size_t left = io.mem_in_n - io.mem_in_pos;
                 bool table = false;
+                s.boff.clear();
                 while (n < left) {
                     if (fh.version == FQZ_VERSION3 && left - n >= 8 && !memcmp(p + n, "\xFF\xFF\xFF\xFF" "FQZX", 8)) { table = true; break; } // the block table: the chain ends here
                     fqz_block_header bh;
@@ -362,6 +364,7 @@ static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *op
                     if (pay > left - n - (size_t)h) { P.fail(FQZ_E_READ_DATA); return; } // compress.go:732
                     const size_t blk = (size_t)h + (size_t)pay;
                     if (n && n + blk > slice) break;
+                    s.boff.push_back(n);
                     n += blk;
                 }
                 if (n >= 0x7FFFFFFFull) { P.fail(FQZ_E_TOO_LARGE); return; }
@@ -374,6 +377,7 @@ static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *op
                 size_t cap = slice + (64u << 20);
                 if (s.h_in.ensure(cap)) { P.fail(FQZ_E_NOMEM); return; }
                 uint8_t *h_in = s.h_in.as<uint8_t>();
+                s.boff.clear();
                 for (;;) {
                     uint8_t bhb[36];
                     if (!pending.empty()) { memcpy(bhb, pending.data(), hs); pending.clear(); }
@@ -404,6 +408,7 @@ static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *op
                     long r = io.read_full(h_in + n + hs, (size_t)pay);
                     if (r < 0) { P.fail((int)r); return; }
                     if ((unsigned long long)r < pay) { P.fail(FQZ_E_READ_DATA); return; }
+                    s.boff.push_back(n);
                     n += blk;
                 }
                 if (s.d_new.ensure(n + 64)) { P.fail(FQZ_E_NOMEM); return; }
@@ -426,8 +431,10 @@ static int decompress_job(fqz_ctx *ctx, Io &io, const fqz_decompress_options *op
         if (s.n_new) {
             fqz_batch_result res;
             lane->dec.skip_assemble = io.count_only; // only the size is wanted: everything but the text assembly
+            lane->dec.hint_off = s.boff.data(); lane->dec.hint_n = s.boff.size(); // (the feeder walked the block headers already)
             rc = fqz_dec_launch(lane, s.d_new.as<uint8_t>(), s.n_new, fh.version, enc, nullptr, 0, lane->stream);
             if (!rc) rc = fqz_dec_finish(lane, &res);
+            lane->dec.hint_off = nullptr; lane->dec.hint_n = 0;
             lane->dec.skip_assemble = false;
             if (rc) { P.fail(rc); break; }
             s.d_res = lane->dec.d_out;
