@@ -420,6 +420,21 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
         const uint32_t cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)(C.sym[0] & 0xFF)); // wave-uniform candidate byte
         const uint32_t cand4 = cand * 0x01010101u;
         uint32_t n_cand = 0, differs = 0;
+        const bool full_chunk = !HDR && mk == FQZ_CHUNK; // (every lane holds 64 bytes: no validity masks to work out - a fifth of the pass's instructions)
+        if (full_chunk) {
+#pragma unroll
+            for (int d = 0; d < 16; d++) {
+                const uint32_t eq = zero_bytes(C.sym[d] ^ cand4);
+                differs |= ~zero_bytes(C.sym[d] ^ b0) & 0x80808080u;
+                n_cand += __popc(eq);
+                uint32_t other = 0x80808080u & ~eq; // 0x80 per byte that still needs an atomic
+                while (other) {
+                    int bit = __ffs(other) - 1; // 7, 15, 23 or 31
+                    other &= other - 1;
+                    atomicAdd(&S.ctab[(C.sym[d] >> (bit - 7)) & 0xFF], 1u);
+                }
+            }
+        } else {
 #pragma unroll
         for (int d = 0; d < 16; d++) {
             const uint32_t valid = C.cnt >= 4u * d + 4 ? 0x80808080u : (C.cnt > 4u * d ? (0x80808080u >> (8 * (4 * d + 4 - C.cnt))) : 0u);
@@ -432,6 +447,7 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
                 other &= other - 1;
                 atomicAdd(&S.ctab[(C.sym[d] >> (bit - 7)) & 0xFF], 1u);
             }
+        }
         }
         n_cand = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(n_cand), 63); // (DPP: no trip through the LDS crossbar)
         if (lane == 0 && n_cand) atomicAdd(&S.ctab[cand], n_cand);
