@@ -703,6 +703,11 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
             for (uint32_t i = t; i < OUT_WORDS; i += 256) S.out[i] = 0;
             // ---- pass 1: bits per lane, per stream (wave w encodes stream w)
             uint32_t my_bits = 0;
+            if (ml == FQZ_CHUNK) { // (a full chunk - uniform for the workgroup: every lane holds 64 symbols, no per-dword tests)
+#pragma unroll
+                for (int d = 0; d < 16; d++)
+                    my_bits += (S.ctab[C.sym[d] & 0xFF] >> 16) + (S.ctab[(C.sym[d] >> 8) & 0xFF] >> 16) + (S.ctab[(C.sym[d] >> 16) & 0xFF] >> 16) + (S.ctab[C.sym[d] >> 24] >> 16);
+            } else {
 #pragma unroll
             for (int d = 0; d < 16; d++) {
                 if (4u * d + 4 <= C.cnt) {
@@ -711,6 +716,7 @@ __device__ __forceinline__ void entropy_encode_group(EntropyLds &S, const uint8_
                 } else if (4u * d < C.cnt) {
                     for (uint32_t z = 0; z < C.cnt - 4u * d; z++) my_bits += S.ctab[(C.sym[d] >> (8 * z)) & 0xFF] >> 16;
                 }
+            }
             }
             const uint32_t incl = wave_incl_scan(my_bits);
             const uint32_t tot_bits = __shfl(incl, 63, WAVE);
