@@ -333,6 +333,7 @@ def main():
     d_backs = [torch.empty(b.size + 4096, dtype=torch.uint8, device=dev) for b in batches]
     dress = [BatchResult() for _ in batches]
     dkern = {}
+    torch.cuda.synchronize()  # (the copies above ran on torch's stream; the library decodes on its own non-blocking stream)
 
     def decode_step():
         for i in range(len(batches)):
@@ -523,6 +524,7 @@ def main():
                 zs = [dos[i][: int(rs[i].out_len)].clone() for i in range(len(texts))]
                 bk = [torch.empty(t.size + 4096, dtype=torch.uint8, device=dev) for t in texts]
                 ds = [BatchResult() for _ in texts]
+                torch.cuda.synchronize()  # (torch's copies before the library's streams read them)
 
                 def dec():
                     for i in range(len(texts)):

@@ -326,6 +326,7 @@ def test_block_offset_hint_is_a_hint(fq):
         assert res.n_blocks == 8 and offs[0] == 0 and all(offs[i] + lens[i] == offs[i + 1] for i in range(7))
         def dec(block_off):
             d_back.zero_()
+            torch.cuda.synchronize()  # (torch's stream and the library's are not ordered)
             r = fq.compress.decode_batch_dev(d_out.data_ptr(), int(res.out_len), d_back.data_ptr(), d_back.numel(), version=version,
                                              qual_encoding=res.qual_encoding, block_off=block_off)
             return d_back[: r.out_len].cpu().numpy().tobytes()
@@ -345,5 +346,6 @@ def test_block_offset_hint_is_a_hint(fq):
         hdr = [int.from_bytes(body[pos + 4 * i: pos + 4 * i + 4].tobytes(), "little") for i in range(9)]
         pos += 36 + sum(hdr[1:7])
     d_back.zero_()
+    torch.cuda.synchronize()
     r = fq.compress.decode_batch_dev(d_body.data_ptr(), d_body.numel(), d_back.data_ptr(), d_back.numel(), version=3, qual_encoding=0, block_off=offs3)
     assert d_back[: r.out_len].cpu().numpy().tobytes() == text

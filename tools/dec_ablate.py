@@ -12,6 +12,7 @@ out = torch.empty(text.size, dtype=torch.uint8, device=dev)
 ctx = fq.Ctx(0)
 res = compress.encode_batch_dev(t.data_ptr(), t.numel(), out.data_ptr(), out.numel(), ctx=ctx)
 z = out[: res.out_len].clone()
+torch.cuda.synchronize()  # (torch's copy before the library's stream reads it)
 back = torch.empty(text.size + 4096, dtype=torch.uint8, device=dev)
 for mode in [0, 2, 1, 0]:
     os.environ["FQZ_DBG_DEC"] = str(mode)

@@ -26,6 +26,7 @@ kern = ctx.profile_read(); ctx.profile(False)
 print("encode %.3f ms  %.1f GB/s  ratio %.3f  records %d" % (dt * 1e3, text.size / dt / 1e9, text.size / res.out_len, res.n_records))
 print({n: round(v[0] / v[1], 3) for n, v in kern.items()})
 z = d_out[: res.out_len].clone()
+torch.cuda.synchronize()  # (torch's copy before the library's stream reads it)
 back = torch.empty(text.size + 4096, dtype=torch.uint8, device=dev)
 dres = BatchResult()
 def dec():
